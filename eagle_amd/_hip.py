@@ -1,0 +1,90 @@
+"""ctypes binding of libeagle_hip.so (the C ABI declared in include/eagle_hip.h).
+
+The library is mandatory: there is no CPU or eager fallback anywhere in eagle_amd.  If it is
+missing (not built) every kernel call raises ``HipLibraryMissing``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+from typing import Optional
+
+import torch
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libeagle_hip.so")
+
+_ERR = {1: "EAGLE_ERR_SHAPE (operand shapes outside what the kernel assumes)",
+        2: "EAGLE_ERR_LAUNCH (HIP launch failed)", 3: "EAGLE_ERR_ARG (null pointer / bad enum)"}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes).  Mirrors include/eagle_hip.h one to one.
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+SIGNATURES = {
+    "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
+    "eagle_rmsnorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),
+    "eagle_rmsnorm_bwd_workspace_bytes": (L, [I, I]),
+    "eagle_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, P, I, P, I, I, P]),
+    "eagle_attn_decode_lds_bytes": (L, [I]),
+    "eagle_tree_attention_bf16": (I, [P, L, P, P, P, I, P, P, L, I, P, I, P, I, L, P, L, P, L, P,
+                                      I, I, I, I, I, I, I, I, I, P]),
+    "eagle_topk_workspace_bytes": (L, [I, I, I]),
+    "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P]),
+    "eagle_tree_gather_ids": (I, [P, L, P, I, P, I, P]),
+    "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, I, P]),
+    "eagle_kv_compact_bf16": (I, [P, L, L, I, I, I, P, I, P, P, I, P, P]),
+    "eagle_gather_accepted_bf16": (I, [P, I, I, P, I, P, P, I, P]),
+    "eagle_ce_stat_bytes": (I, []),
+    "eagle_ce_partial_bf16": (I, [P, P, L, I, I, I, P, P, I, P, P]),
+    "eagle_ce_combine": (I, [P, I, I, P, P, P, P, P, P]),
+    "eagle_fused_ce_smoothl1_fwd_bf16": (I, [P, P, L, I, I, P, P, I, P, P, P, P, P, P, P]),
+    "eagle_ce_smoothl1_bwd_bf16": (I, [P, P, L, I, I, P, P, P, F, F, P, L, P, P, I, P, P]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -m eagle_amd.build` "
+                "(eagle_amd has no CPU fallback)")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipKernelError("eagle_amd kernels need device tensors (no CPU path)")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise HipKernelError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+def query(name: str, *args):
+    return getattr(lib(), name)(*args)

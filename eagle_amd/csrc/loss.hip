@@ -1,0 +1,312 @@
+// Fused EAGLE training loss at the logits level (gfx950): soft-label cross entropy against the
+// verifier's distribution + smooth-L1 feature loss + argmax agreement, forward and backward.
+//
+// Replaces eagle/train.py:108-123 (== eagle/train_tp.py:90-105):
+//     target_p = softmax(t);  out_logp = log_softmax(o)
+//     ploss = -sum_rows mask * sum_v target_p * out_logp  = sum_rows mask * (lse(o) - sum_v p_v o_v)
+//     vloss = sum_rows mean_d(mask * smooth_l1(predict, target))      (beta = 1, train.py:65)
+//     correct = sum_rows mask * (argmax target_p == argmax out_logp)  (first max index)
+// The reference's eager chain makes ~14 passes over [N,V]; here forward reads both logit tensors
+// exactly once (online softmax, 16-byte loads) and backward reads them once and writes dlogits
+// once: the kernels are HBM-bound and are measured as such.
+//
+// The forward is split as partial-per-vocab-shard + combine so the same kernels serve the
+// vocab-sharded variant: each rank runs ce_partial on its [N, V/R] slice, the
+// [R,N,8] statistics are exchanged, ce_combine merges them.
+#include "common.h"
+
+#define CE_THREADS 256
+#define L2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+struct CeStat {  // 32 bytes per row per shard
+  float m_t, z_t, a, m_o, z_o;
+  int idx_t, idx_o;
+  float vloss;  // mean_d smooth_l1(predict-target) (filled by shard/partial 0 only)
+};
+
+struct TState { float m, z, a; int idx; };
+struct OState { float m, z; int idx; };
+
+__device__ __forceinline__ void merge_t(TState& x, const TState& y) {
+  if (y.m > x.m || (y.m == x.m && y.idx < x.idx)) {
+    const float s = exp2f((x.m - y.m) * L2E);
+    const float xs = (x.m == -INFINITY) ? 0.f : s;
+    x.z = x.z * xs + y.z; x.a = x.a * xs + y.a;
+    if (y.m > x.m) x.idx = y.idx; else x.idx = y.idx < x.idx ? y.idx : x.idx;
+    x.m = y.m;
+  } else {
+    const float s = (y.m == -INFINITY) ? 0.f : exp2f((y.m - x.m) * L2E);
+    x.z += y.z * s; x.a += y.a * s;
+  }
+}
+__device__ __forceinline__ void merge_o(OState& x, const OState& y) {
+  if (y.m > x.m || (y.m == x.m && y.idx < x.idx)) {
+    const float xs = (x.m == -INFINITY) ? 0.f : exp2f((x.m - y.m) * L2E);
+    x.z = x.z * xs + y.z;
+    if (y.m > x.m) x.idx = y.idx; else x.idx = y.idx < x.idx ? y.idx : x.idx;
+    x.m = y.m;
+  } else {
+    const float s = (y.m == -INFINITY) ? 0.f : exp2f((y.m - x.m) * L2E);
+    x.z += y.z * s;
+  }
+}
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  const uint32_t* u = reinterpret_cast<const uint32_t*>(&v);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = lo_bf(u[j]); f[2 * j + 1] = hi_bf(u[j]); }
+}
+
+__device__ __forceinline__ void absorb(TState& ts, OState& os, const float* tf, const float* of, int n, int col0) {
+  float cmt = -INFINITY, cmo = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (j < n) { cmt = fmaxf(cmt, tf[j]); cmo = fmaxf(cmo, of[j]); }
+  if (cmt > ts.m) {
+    const float s = (ts.m == -INFINITY) ? 0.f : exp2f((ts.m - cmt) * L2E);
+    ts.z *= s; ts.a *= s; ts.m = cmt;
+    int f = 0;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) if (j < n && tf[j] == cmt) f = j;
+    ts.idx = col0 + f;
+  }
+  if (cmo > os.m) {
+    const float s = (os.m == -INFINITY) ? 0.f : exp2f((os.m - cmo) * L2E);
+    os.z *= s; os.m = cmo;
+    int f = 0;
+#pragma unroll
+    for (int j = 7; j >= 0; --j) if (j < n && of[j] == cmo) f = j;
+    os.idx = col0 + f;
+  }
+  const float bt = -ts.m * L2E, bo = -os.m * L2E;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (j < n) {
+    const float e = exp2f(fmaf(tf[j], L2E, bt));
+    ts.z += e; ts.a = fmaf(e, of[j], ts.a);
+    os.z += exp2f(fmaf(of[j], L2E, bo));
+  }
+}
+
+// grid: N rows.  t/o: [N, V] bf16 with row stride ld (elements); v0 = global index of column 0.
+__global__ __launch_bounds__(CE_THREADS) void ce_partial_kernel(const bf16_t* __restrict__ t, const bf16_t* __restrict__ o,
+                                                               int64_t ld, int V, int v0,
+                                                               const bf16_t* __restrict__ predict,
+                                                               const bf16_t* __restrict__ target, int D,
+                                                               CeStat* __restrict__ stats) {
+  __shared__ TState sht[4];
+  __shared__ OState sho[4];
+  __shared__ float shv[4];
+  const int64_t row = blockIdx.x;
+  const bf16_t* tr = t + row * ld;
+  const bf16_t* orow = o + row * ld;
+  TState ts = {-INFINITY, 0.f, 0.f, 0x7fffffff};
+  OState os = {-INFINITY, 0.f, 0x7fffffff};
+  const bool vec = ((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(t) & 15) == 0) && ((reinterpret_cast<uintptr_t>(o) & 15) == 0);
+  float tf[8], of[8];
+  if (vec) {
+    const int nfull = V >> 3;
+    for (int c = threadIdx.x; c < nfull; c += CE_THREADS) {
+      const uint4 tv = *reinterpret_cast<const uint4*>(tr + c * 8);
+      const uint4 ov = *reinterpret_cast<const uint4*>(orow + c * 8);
+      unpack8(tv, tf); unpack8(ov, of);
+      absorb(ts, os, tf, of, 8, v0 + c * 8);
+    }
+    const int rem = V & 7;
+    if (rem && threadIdx.x == (nfull % CE_THREADS)) {
+      for (int j = 0; j < rem; ++j) { tf[j] = bf2f(tr[nfull * 8 + j]); of[j] = bf2f(orow[nfull * 8 + j]); }
+      absorb(ts, os, tf, of, rem, v0 + nfull * 8);
+    }
+  } else {
+    const int nch = (V + 7) >> 3;
+    for (int c = threadIdx.x; c < nch; c += CE_THREADS) {
+      const int n = (V - c * 8) < 8 ? (V - c * 8) : 8;
+      for (int j = 0; j < n; ++j) { tf[j] = bf2f(tr[c * 8 + j]); of[j] = bf2f(orow[c * 8 + j]); }
+      absorb(ts, os, tf, of, n, v0 + c * 8);
+    }
+  }
+  // wave reduce
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    TState y = {__shfl_xor(ts.m, off, 64), __shfl_xor(ts.z, off, 64), __shfl_xor(ts.a, off, 64), __shfl_xor(ts.idx, off, 64)};
+    OState w = {__shfl_xor(os.m, off, 64), __shfl_xor(os.z, off, 64), __shfl_xor(os.idx, off, 64)};
+    merge_t(ts, y); merge_o(os, w);
+  }
+  // smooth-L1 feature loss of this row (beta = 1)
+  float vl = 0.f;
+  if (predict) {
+    const bf16_t* pr = predict + row * D;
+    const bf16_t* tg = target + row * D;
+    for (int c = threadIdx.x; c < (D >> 3); c += CE_THREADS) {
+      float pf[8], gf[8];
+      unpack8(*reinterpret_cast<const uint4*>(pr + c * 8), pf);
+      unpack8(*reinterpret_cast<const uint4*>(tg + c * 8), gf);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = pf[j] - gf[j], ad = fabsf(d);
+        vl += ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+      }
+    }
+    vl = wave_sum(vl);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sht[wave] = ts; sho[wave] = os; shv[wave] = vl; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { merge_t(ts, sht[w]); merge_o(os, sho[w]); vl += shv[w]; }
+    CeStat s;
+    s.m_t = ts.m; s.z_t = ts.z; s.a = ts.a; s.m_o = os.m; s.z_o = os.z; s.idx_t = ts.idx; s.idx_o = os.idx;
+    s.vloss = predict ? vl / (float)D : 0.f;
+    stats[row] = s;
+  }
+}
+
+// Merge R shards' statistics and reduce over rows (single workgroup: N is a micro-batch).
+//   lse_t/lse_o [N] (natural log), row_out [N][4] = {ploss_row, vloss_row, agree, 0}
+//   sums[4] = {sum mask*ploss, sum mask*vloss, sum mask*agree, sum mask}
+__global__ __launch_bounds__(1024) void ce_combine_kernel(const CeStat* __restrict__ stats, int R, int N,
+                                                          const float* __restrict__ mask, float* __restrict__ lse_t,
+                                                          float* __restrict__ lse_o, float* __restrict__ row_out,
+                                                          float* __restrict__ sums) {
+  __shared__ double sh[4][16];
+  double acc[4] = {0, 0, 0, 0};
+  for (int n = threadIdx.x; n < N; n += blockDim.x) {
+    const CeStat s0 = stats[n];
+    TState ts = {s0.m_t, s0.z_t, s0.a, s0.idx_t};
+    OState os = {s0.m_o, s0.z_o, s0.idx_o};
+    for (int r = 1; r < R; ++r) {
+      const CeStat s = stats[(int64_t)r * N + n];
+      TState y = {s.m_t, s.z_t, s.a, s.idx_t};
+      OState w = {s.m_o, s.z_o, s.idx_o};
+      merge_t(ts, y); merge_o(os, w);
+    }
+    const float lt = ts.m + logf(ts.z), lo = os.m + logf(os.z);
+    const float pl = lo - ts.a / ts.z;
+    const float ag = ts.idx == os.idx ? 1.f : 0.f;
+    const float mk = mask ? mask[n] : 1.f;
+    lse_t[n] = lt; lse_o[n] = lo;
+    if (row_out) { row_out[n * 4 + 0] = pl; row_out[n * 4 + 1] = s0.vloss; row_out[n * 4 + 2] = ag; row_out[n * 4 + 3] = 0.f; }
+    acc[0] += (double)mk * pl; acc[1] += (double)mk * s0.vloss; acc[2] += (double)mk * ag; acc[3] += mk;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) sh[k][wave] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double v = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) v += sh[threadIdx.x][w];
+    sums[threadIdx.x] = (float)v;
+  }
+}
+
+// dlogits[n][v] = mask[n] * g_p * (softmax(o) - softmax(t));  dpred_v[n][d] = mask[n]*g_v*clamp(p-t,-1,1)/D
+// grid: N rows.  May run in place (dlogits == o).
+__global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const bf16_t* __restrict__ t, const bf16_t* o,
+                                                           int64_t ld, int V, const float* __restrict__ lse_t,
+                                                           const float* __restrict__ lse_o, const float* __restrict__ mask,
+                                                           float g_p, float g_v, bf16_t* dlogits, int64_t ldd,
+                                                           const bf16_t* __restrict__ predict, const bf16_t* __restrict__ target,
+                                                           int D, bf16_t* __restrict__ dpred) {
+  const int64_t row = blockIdx.x;
+  const float mk = mask ? mask[row] : 1.f;
+  const bf16_t* tr = t + row * ld;
+  const bf16_t* orow = o + row * ld;
+  bf16_t* dr = dlogits + row * ldd;
+  const float gp = mk * g_p;
+  const float bt = -lse_t[row] * L2E, bo = -lse_o[row] * L2E;
+  const bool vec = ((ld & 7) == 0) && ((ldd & 7) == 0) && ((reinterpret_cast<uintptr_t>(t) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(o) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dlogits) & 15) == 0);
+  if (vec) {
+    const int nfull = V >> 3;
+    if (gp == 0.f) {
+      for (int c = threadIdx.x; c < nfull; c += CE_THREADS) *reinterpret_cast<uint4*>(dr + c * 8) = make_uint4(0, 0, 0, 0);
+    } else {
+      for (int c = threadIdx.x; c < nfull; c += CE_THREADS) {
+        float tf[8], of[8];
+        unpack8(*reinterpret_cast<const uint4*>(tr + c * 8), tf);
+        unpack8(*reinterpret_cast<const uint4*>(orow + c * 8), of);
+        uint4 dv;
+        uint32_t* du = reinterpret_cast<uint32_t*>(&dv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float d0 = gp * (exp2f(fmaf(of[2 * j], L2E, bo)) - exp2f(fmaf(tf[2 * j], L2E, bt)));
+          const float d1 = gp * (exp2f(fmaf(of[2 * j + 1], L2E, bo)) - exp2f(fmaf(tf[2 * j + 1], L2E, bt)));
+          du[j] = pack2bf(d0, d1);
+        }
+        *reinterpret_cast<uint4*>(dr + c * 8) = dv;
+      }
+    }
+    for (int v = nfull * 8 + threadIdx.x; v < V; v += CE_THREADS)
+      dr[v] = f2bf(gp * (exp2f(fmaf(bf2f(orow[v]), L2E, bo)) - exp2f(fmaf(bf2f(tr[v]), L2E, bt))));
+  } else {
+    for (int v = threadIdx.x; v < V; v += CE_THREADS)
+      dr[v] = f2bf(gp * (exp2f(fmaf(bf2f(orow[v]), L2E, bo)) - exp2f(fmaf(bf2f(tr[v]), L2E, bt))));
+  }
+  if (dpred) {
+    const float gv = mk * g_v / (float)D;
+    const bf16_t* pr = predict + row * D;
+    const bf16_t* tg = target + row * D;
+    for (int c = threadIdx.x; c < (D >> 3); c += CE_THREADS) {
+      float pf[8], gf[8];
+      unpack8(*reinterpret_cast<const uint4*>(pr + c * 8), pf);
+      unpack8(*reinterpret_cast<const uint4*>(tg + c * 8), gf);
+      uint4 dv;
+      uint32_t* du = reinterpret_cast<uint32_t*>(&dv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = fminf(fmaxf(pf[2 * j] - gf[2 * j], -1.f), 1.f) * gv;
+        const float b = fminf(fmaxf(pf[2 * j + 1] - gf[2 * j + 1], -1.f), 1.f) * gv;
+        du[j] = pack2bf(a, b);
+      }
+      *reinterpret_cast<uint4*>(dpred + row * D + c * 8) = dv;
+    }
+  }
+}
+
+extern "C" int eagle_ce_stat_bytes() { return (int)sizeof(CeStat); }
+
+extern "C" int eagle_ce_partial_bf16(const void* t_logits, const void* o_logits, int64_t ld, int N, int V, int v0,
+                                     const void* predict, const void* target, int D, void* stats, hipStream_t stream) {
+  if (!t_logits || !o_logits || !stats) return EAGLE_ERR_ARG;
+  if (N < 1 || V < 1 || ld < V) return EAGLE_ERR_SHAPE;
+  if (predict && (!target || D < 8 || (D & 7))) return EAGLE_ERR_SHAPE;
+  hipLaunchKernelGGL(ce_partial_kernel, dim3(N), dim3(CE_THREADS), 0, stream, (const bf16_t*)t_logits, (const bf16_t*)o_logits,
+                     ld, V, v0, (const bf16_t*)predict, (const bf16_t*)target, D, (CeStat*)stats);
+  return eagle_check_launch();
+}
+
+extern "C" int eagle_ce_combine(const void* stats, int R, int N, const float* mask, float* lse_t, float* lse_o,
+                                float* row_out, float* sums, hipStream_t stream) {
+  if (!stats || !lse_t || !lse_o || !sums) return EAGLE_ERR_ARG;
+  if (R < 1 || N < 1) return EAGLE_ERR_SHAPE;
+  hipLaunchKernelGGL(ce_combine_kernel, dim3(1), dim3(1024), 0, stream, (const CeStat*)stats, R, N, mask, lse_t, lse_o,
+                     row_out, sums);
+  return eagle_check_launch();
+}
+
+extern "C" int eagle_ce_smoothl1_bwd_bf16(const void* t_logits, const void* o_logits, int64_t ld, int N, int V,
+                                          const float* lse_t, const float* lse_o, const float* mask, float g_p, float g_v,
+                                          void* dlogits, int64_t ldd, const void* predict, const void* target, int D,
+                                          void* dpredict, hipStream_t stream) {
+  if (!t_logits || !o_logits || !lse_t || !lse_o || !dlogits) return EAGLE_ERR_ARG;
+  if (N < 1 || V < 1 || ld < V || ldd < V) return EAGLE_ERR_SHAPE;
+  if (dpredict && (!predict || !target || D < 8 || (D & 7))) return EAGLE_ERR_SHAPE;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(N), dim3(CE_THREADS), 0, stream, (const bf16_t*)t_logits, (const bf16_t*)o_logits, ld,
+                     V, lse_t, lse_o, mask, g_p, g_v, (bf16_t*)dlogits, ldd, (const bf16_t*)predict, (const bf16_t*)target, D,
+                     (bf16_t*)dpredict);
+  return eagle_check_launch();
+}
+
+// Single-device forward = partial (R = 1) + combine.
+extern "C" int eagle_fused_ce_smoothl1_fwd_bf16(const void* t_logits, const void* o_logits, int64_t ld, int N, int V,
+                                                const void* predict, const void* target, int D, const float* mask,
+                                                void* stats_ws, float* lse_t, float* lse_o, float* row_out, float* sums,
+                                                hipStream_t stream) {
+  int rc = eagle_ce_partial_bf16(t_logits, o_logits, ld, N, V, 0, predict, target, D, stats_ws, stream);
+  if (rc) return rc;
+  return eagle_ce_combine(stats_ws, 1, N, mask, lse_t, lse_o, row_out, sums, stream);
+}

@@ -1,0 +1,285 @@
+"""MI355X-native drop-in for ``eagle/llama2.py``'s ``Llama2Model`` (the EAGLE-1 draft head).
+
+Same constructor, ``forward`` signature, return convention, attributes (``tree_mask``,
+``reset()``, ``init_tree()``, ``gradient_checkpointing``, ``embed_tokens``, ``layers``, ``fc``)
+and ``state_dict`` keys as the reference (eagle/llama2.py:404-587), so checkpoints in the
+SGLang-compatible layout load unchanged.  The compute is different: every op of the forward runs
+in hand-written HIP kernels reached through the C ABI (include/eagle_hip.h):
+
+    fc(cat(embed_tokens[ids], hidden))      -> eagle_gemm_skinny_bf16 (row gather + concat fused)
+    q|k|v projection (one packed weight)    -> eagle_gemm_skinny_bf16
+    RoPE + cache append + masked attention  -> eagle_tree_attention_bf16
+    o_proj + residual                       -> eagle_gemm_skinny_bf16 (residual epilogue)
+    post_attention_layernorm                -> eagle_rmsnorm_fwd_bf16
+    silu(gate)*up                           -> eagle_gemm_skinny_bf16 (SiLU*mul epilogue)
+    down_proj + residual                    -> eagle_gemm_skinny_bf16
+
+The KV cache is a preallocated [B, kv_heads, cap, hd] buffer per layer; ``forward`` returns
+views ``[:, :, :kv_len]`` with the reference's shapes.  A view handed back as
+``past_key_values`` is recognised and appended to in place (no torch.cat, eagle/llama2.py:236-239);
+foreign tensors are copied in first.  Rows at or beyond a returned view's length may be
+overwritten by a later call that restarts from a shorter past (tree expansion does exactly that).
+
+bf16 on a HIP device only.  There is no CPU / eager fallback: without the built library or on
+CPU tensors ``forward`` raises.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from .tree import TreeBuffers, generate_tree_buffers, mc_sim_7b_63
+
+top_k = 10  # eagle/llama2.py:11
+
+
+class LlamaRMSNorm(nn.Module):
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, hidden_states):
+        return ops.rmsnorm(hidden_states, self.weight, self.variance_epsilon)
+
+
+class LlamaAttention(nn.Module):
+    """Parameter container with the reference's names (eagle/llama2.py:152-171)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = getattr(config, "num_key_value_heads", None) or self.num_heads
+        if self.head_dim * self.num_heads != self.hidden_size:
+            raise ValueError(
+                f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size}"
+                f" and `num_heads`: {self.num_heads}).")
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=False)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=False)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=False)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_act != "silu":
+            raise NotImplementedError("only hidden_act='silu' (both shipped configs) is implemented")
+        self.gate_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(config.hidden_size, config.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(config.intermediate_size, config.hidden_size, bias=False)
+
+
+class LlamaDecoderLayer(nn.Module):
+    def __init__(self, config, index):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.self_attn = LlamaAttention(config=config)
+        self.mlp = LlamaMLP(config)
+        self.index = index
+        if self.index != 0:  # layer 0 has no input_layernorm (eagle/llama2.py:344-345)
+            self.input_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = LlamaRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+
+class _LayerCache:
+    __slots__ = ("k", "v", "cap")
+
+    def __init__(self, B, HK, cap, hd, device):
+        self.k = torch.zeros((B, HK, cap, hd), dtype=torch.bfloat16, device=device)
+        self.v = torch.zeros((B, HK, cap, hd), dtype=torch.bfloat16, device=device)
+        self.cap = cap
+
+
+class Llama2Model(nn.Module):
+    def __init__(self, config, load_emb=False, path=None, bias=True):
+        super().__init__()
+        if getattr(config, "rope_scaling", None) not in (None, {}) and \
+                getattr(config, "rope_scaling", {}).get("rope_type", "default") != "default":
+            raise NotImplementedError("rope_scaling variants are outside the hot path (SURVEY.md row 6b)")
+        if getattr(config, "pretraining_tp", 1) != 1:
+            raise NotImplementedError("pretraining_tp > 1 is outside the hot path (SURVEY.md row 6c)")
+        self.config = config
+        self.gradient_checkpointing = True
+        self.padding_idx = config.pad_token_id
+        self.vocab_size = config.vocab_size
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, self.padding_idx)
+        if load_emb:
+            self.embed_tokens.weight.data = _load_verifier_tensor(path, "model.embed_tokens.weight").float()
+        self.layers = nn.ModuleList([LlamaDecoderLayer(config, index) for index in range(config.num_hidden_layers)])
+        self.fc = nn.Linear(2 * config.hidden_size, config.hidden_size, bias=bias)
+        for param in self.embed_tokens.parameters():
+            param.requires_grad = False
+        self.tree_mask = None
+        self._caches: List[_LayerCache] = []
+        self._packed = {}
+        self._rope = None
+        self._err = None
+
+    # ------------------------------------------------------------------ tree hooks
+    def init_tree(self, tree=mc_sim_7b_63, expand: str = "wchild"):
+        self.tree = tree
+        self.tree_buffers = generate_tree_buffers(self.tree, self.embed_tokens.weight.device, expand=expand)
+        self.tree_buffer = self.tree_buffers.as_dict()
+
+    def reset(self):
+        self.tree_mask = None
+
+    # ------------------------------------------------------------------ helpers
+    def _dims(self):
+        a = self.layers[0].self_attn
+        return a.num_heads, a.num_key_value_heads, a.head_dim
+
+    def _rope_tables(self, n_pos: int, device):
+        if self._rope is None or self._rope[0].shape[0] < n_pos or self._rope[0].device != device:
+            n = max(n_pos, getattr(self.config, "max_position_embeddings", 2048))
+            base = float(getattr(self.config, "rope_theta", 10000.0) or 10000.0)
+            self._rope = ops.rope_tables(self._dims()[2], n, base=base, device=device)
+        return self._rope
+
+    def _packed_weights(self, li: int):
+        """q|k|v stacked into one [ (H+2HK)*hd, D ] weight so the projection is one weight pass.
+        Rebuilt when any source parameter changes (in-place update or reassignment)."""
+        a = self.layers[li].self_attn
+        srcs = (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
+        key = tuple((w.data_ptr(), w._version) for w in srcs)
+        hit = self._packed.get(li)
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([w.detach() for w in srcs], dim=0).contiguous())
+            self._packed[li] = hit
+        return hit[1]
+
+    def _cache_for(self, li: int, B: int, need: int, device, past) -> _LayerCache:
+        H, HK, hd = self._dims()
+        while len(self._caches) <= li:
+            self._caches.append(None)
+        c = self._caches[li]
+        ours = (c is not None and past is not None and past[0].data_ptr() == c.k.data_ptr()
+                and past[1].data_ptr() == c.v.data_ptr() and past[0].stride() == c.k.stride()
+                and past[0].shape[0] == B)
+        if c is None or c.k.shape[0] != B or c.cap < need or c.k.device != device:
+            cap = max(need, getattr(self.config, "max_position_embeddings", 2048))
+            cap = (cap + 255) // 256 * 256
+            nc = _LayerCache(B, HK, cap, hd, device)
+            if past is not None:
+                pl = past[0].shape[2]
+                nc.k[:, :, :pl].copy_(past[0])
+                nc.v[:, :, :pl].copy_(past[1])
+            self._caches[li] = c = nc
+        elif past is not None and not ours:
+            pl = past[0].shape[2]
+            c.k[:, :, :pl].copy_(past[0])
+            c.v[:, :, :pl].copy_(past[1])
+        return c
+
+    # ------------------------------------------------------------------ forward
+    def forward(
+        self,
+        hidden_states,
+        input_ids,
+        attention_mask: Optional[torch.Tensor] = None,
+        position_ids: Optional[torch.LongTensor] = None,
+        past_key_values: Optional[List[torch.FloatTensor]] = None,
+        inputs_embeds: Optional[torch.FloatTensor] = None,
+        use_cache: Optional[bool] = None,
+        output_attentions: Optional[bool] = None,
+        output_hidden_states: Optional[bool] = None,
+        return_dict: Optional[bool] = None,
+        std=None,
+    ):
+        if torch.is_grad_enabled() and self.training:
+            from .train import draft_forward_train  # autograd path (MFMA GEMMs + flash attention)
+            if past_key_values is not None or use_cache:
+                raise ValueError("training forward does not take a KV cache (eagle/train.py:105)")
+            return draft_forward_train(self, hidden_states, input_ids, attention_mask, position_ids)
+        if output_attentions:
+            raise NotImplementedError("attention weights are never materialised by the fused kernel")
+        if not hidden_states.is_cuda:
+            raise ops._hip.HipKernelError("Llama2Model.forward needs device tensors: eagle_amd has no CPU path")
+        if hidden_states.dtype != torch.bfloat16:
+            raise TypeError("eagle_amd computes in bf16 only (cast the model and inputs to torch.bfloat16)")
+        B, q_len, D = hidden_states.shape
+        dev = hidden_states.device
+        H, HK, hd = self._dims()
+        past_len = 0 if past_key_values is None else past_key_values[0][0].shape[2]
+        total = past_len + q_len
+        if position_ids is None:
+            pos = torch.arange(past_len, total, dtype=torch.long, device=dev).repeat(B)
+        else:
+            pos = position_ids.view(-1, q_len).long()
+            pos = (pos.expand(B, q_len) if pos.shape[0] == 1 else pos).reshape(-1).contiguous()
+            if pos.numel() != B * q_len:
+                raise ValueError(f"position_ids has {pos.numel()} entries for {B}x{q_len} rows")
+        pad = None
+        if attention_mask is not None:
+            if tuple(attention_mask.shape) != (B, total):
+                raise ValueError(f"Attention mask should be of size {(B, total)}, but is {tuple(attention_mask.shape)}")
+            pad = attention_mask.to(torch.uint8).contiguous()
+        tmask = None
+        if getattr(self, "tree_mask", None) is not None:
+            tm = self.tree_mask
+            if q_len > 16:
+                raise ValueError("tree_mask steps are limited to 16 query rows")
+            if tm.dim() != 4 or tm.shape[2] != q_len or tm.shape[0] not in (1, B) or tm.shape[-1] > total:
+                raise IndexError(f"tree_mask {tuple(tm.shape)} does not match [B,1,{q_len},T<= {total}]")
+            if tm.shape[0] == 1 and B > 1:
+                raise IndexError("tree_mask must carry the batch dimension, as the reference's boolean index needs")
+            tmask = (tm[:, 0] != 0).to(torch.uint8).contiguous()
+            tmask = tmask[0] if B == 1 else tmask
+        cos, sin = self._rope_tables(total, dev)
+        if self._err is None or self._err.device != dev:
+            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        ids = input_ids.reshape(-1)
+        if ids.dtype != torch.int64:
+            ids = ids.long()
+        ids = ids.contiguous()
+        hs = hidden_states.reshape(B * q_len, D)
+        if not hs.is_contiguous():
+            hs = hs.contiguous()
+        emb_w = self.embed_tokens.weight
+        if emb_w.dtype != torch.bfloat16:
+            raise TypeError("embed_tokens must be bf16 (cast the model with .to(torch.bfloat16))")
+        M = B * q_len
+        # fc(cat(embed_tokens(ids), hidden)) -- eagle/llama2.py:515, :537-542
+        x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=ids, x1=hs, M=M)
+        past_dev = torch.full((B,), past_len, dtype=torch.int32, device=dev)
+        next_cache = () if use_cache else None
+        for li, layer in enumerate(self.layers):
+            a = layer.self_attn
+            past = None if past_key_values is None else past_key_values[li]
+            cache = self._cache_for(li, B, total, dev, past)
+            xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
+            qkv = ops.linear_skinny(xin, self._packed_weights(li))
+            attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
+            for r0 in range(0, q_len, 16):
+                mq = min(16, q_len - r0)
+                ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, r0, tmask, pad, attn, self._err,
+                                   B, mq, H, HK, hd, past_len + r0 + mq, True, q_len, r0)
+            x = ops.linear_skinny(attn, a.o_proj.weight, res=x)
+            xn = ops.rmsnorm(x, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
+            act = ops.linear_skinny(xn, layer.mlp.gate_proj.weight, W2=layer.mlp.up_proj.weight)
+            x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x)
+            if use_cache:
+                next_cache += ((cache.k[:, :, :total], cache.v[:, :, :total]),)
+        out = x.view(B, q_len, D)
+        if use_cache:
+            return out, next_cache
+        return out
+
+
+def _load_verifier_tensor(path, name: str) -> torch.Tensor:
+    """Read one tensor of the verifier checkpoint by its weight-map entry (contract of
+    eagle/llama2.py:415-434 for the embedding and eagle/train.py:215-228 for lm_head)."""
+    from safetensors import safe_open
+
+    with open(os.path.join(path, "model.safetensors.index.json"), "r") as f:
+        shard = json.loads(f.read())["weight_map"][name]
+    with safe_open(os.path.join(path, shard), framework="pt", device="cpu") as f:
+        return f.get_tensor(name)

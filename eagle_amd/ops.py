@@ -1,0 +1,235 @@
+"""Thin tensor-level wrappers over the C ABI (include/eagle_hip.h).
+
+Every function launches hand-written HIP kernels on the current torch stream; torch is used
+only for device memory and streams.  There is no CPU path: non-device tensors raise.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _hip
+from ._hip import call, ptr, query, stream
+
+BF16 = torch.bfloat16
+EPI_LINEAR, EPI_SILU_MUL = 0, 1
+
+
+def _chk(t: torch.Tensor, name: str, dtype=BF16):
+    if not t.is_cuda:
+        raise _hip.HipKernelError(f"{name}: device tensor required (eagle_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                  res: Optional[torch.Tensor] = None, W2: Optional[torch.Tensor] = None,
+                  idx0: Optional[torch.Tensor] = None, x1: Optional[torch.Tensor] = None,
+                  idx1: Optional[torch.Tensor] = None, M: Optional[int] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N] = epi(cat(x[idx0], x1[idx1]) @ W^T).  x [*, K0] row-major; W [N, K]."""
+    _chk(x, "x"), _chk(W, "W")
+    N, K = W.shape
+    K0 = x.shape[-1]
+    if x1 is not None:
+        _chk(x1, "x1")
+        if K0 + x1.shape[-1] != K:
+            raise ValueError(f"cat width {K0}+{x1.shape[-1]} != K={K}")
+    elif K0 != K:
+        raise ValueError(f"x width {K0} != K={K}")
+    if M is None:
+        M = idx0.numel() if idx0 is not None else x.shape[0]
+    if x.stride(-1) != 1 or W.stride(1) != 1 or W.stride(0) != K:
+        raise ValueError("x rows and W must be contiguous along K")
+    for i in (idx0, idx1):
+        if i is not None and (i.dtype != torch.int64 or not i.is_contiguous()):
+            raise TypeError("row index arrays must be contiguous int64")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=x.device)
+    epi = EPI_SILU_MUL if W2 is not None else EPI_LINEAR
+    call("eagle_gemm_skinny_bf16", ptr(x), ptr(idx0), x.stride(0) if x.dim() > 1 else K0, K0,
+         ptr(x1), ptr(idx1), (x1.stride(0) if x1 is not None else 0),
+         ptr(W), ptr(W2), ptr(bias), ptr(res), (res.stride(0) if res is not None else 0),
+         ptr(out), out.stride(0), M, N, K, epi, stream())
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, want_rstd: bool = False):
+    _chk(x, "x"), _chk(w, "w")
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = torch.empty_like(x2)
+    rstd = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device) if want_rstd else None
+    call("eagle_rmsnorm_fwd_bf16", ptr(x2), ptr(w), ptr(y), ptr(rstd), x2.shape[0], D, float(eps), stream())
+    y = y.view(x.shape)
+    return (y, rstd) if want_rstd else y
+
+
+def tree_attention(qkv: torch.Tensor, position_ids: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                   kcache: torch.Tensor, vcache: torch.Tensor, past_len: torch.Tensor, past_off: int,
+                   tree_mask: Optional[torch.Tensor], pad_mask: Optional[torch.Tensor], out: torch.Tensor,
+                   err_flag: Optional[torch.Tensor], B: int, M: int, H: int, HK: int, hd: int, max_kv: int,
+                   causal: bool, rows_per_req: int, row_off: int) -> None:
+    """See include/eagle_hip.h: eagle_tree_attention_bf16."""
+    _chk(qkv, "qkv"), _chk(kcache, "kcache"), _chk(vcache, "vcache"), _chk(out, "out")
+    cap = kcache.shape[2]
+    T, tmb = 0, 0
+    if tree_mask is not None:
+        if tree_mask.dtype != torch.uint8 or not tree_mask.is_contiguous():
+            raise TypeError("tree_mask must be contiguous uint8 [M,T] or [B,M,T]")
+        T = tree_mask.shape[-1]
+        tmb = tree_mask.stride(0) if tree_mask.dim() == 3 else 0
+    if pad_mask is not None and (pad_mask.dtype != torch.uint8 or pad_mask.stride(-1) != 1):
+        raise TypeError("pad_mask must be uint8 [B, kv]")
+    call("eagle_tree_attention_bf16", ptr(qkv), qkv.stride(0), ptr(position_ids), ptr(cos), ptr(sin), cos.shape[0],
+         ptr(kcache), ptr(vcache), kcache.stride(0), cap, ptr(past_len), past_off,
+         ptr(tree_mask), T, tmb, ptr(pad_mask), (pad_mask.stride(0) if pad_mask is not None else 0),
+         ptr(out), out.stride(0), ptr(err_flag), B, M, H, HK, hd, max_kv, int(causal), rows_per_req, row_off, stream())
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = w
+    return w
+
+
+def topk(logits: torch.Tensor, k: int, want_values: bool = True,
+         out_idx: Optional[torch.Tensor] = None, out_val: Optional[torch.Tensor] = None,
+         workspace: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+    """(values, indices) of the k largest per row: value desc, index asc.  logits [rows, V]."""
+    if logits.dtype == BF16:
+        dt = 0
+    elif logits.dtype == torch.float32:
+        dt = 1
+    else:
+        raise TypeError("topk: bf16 or fp32 logits")
+    if not logits.is_cuda:
+        raise _hip.HipKernelError("topk: device tensor required")
+    rows, V = logits.shape
+    if logits.stride(1) != 1:
+        raise ValueError("topk: logits rows must be contiguous")
+    if out_idx is None:
+        out_idx = torch.empty((rows, k), dtype=torch.int64, device=logits.device)
+    if want_values and out_val is None:
+        out_val = torch.empty((rows, k), dtype=logits.dtype, device=logits.device)
+    nb = query("eagle_topk_workspace_bytes", rows, V, k)
+    ws = workspace if workspace is not None else _workspace(nb, logits.device)
+    call("eagle_topk_vocab", ptr(logits), logits.stride(0), dt, rows, V, k, ptr(out_idx),
+         ptr(out_val) if want_values else None, ptr(ws), stream())
+    return (out_val if want_values else None), out_idx
+
+
+def first_argmax(logits: torch.Tensor) -> torch.Tensor:
+    return topk(logits, 1, want_values=False)[1][:, 0]
+
+
+def tree_gather_ids(flat_ids: torch.Tensor, tree_idx: torch.Tensor, B: int = 1, out=None) -> torch.Tensor:
+    n = tree_idx.numel()
+    flat = flat_ids.reshape(B, -1)
+    if out is None:
+        out = torch.empty((B, n), dtype=torch.int64, device=flat_ids.device)
+    call("eagle_tree_gather_ids", ptr(flat), flat.stride(0), ptr(tree_idx), n, ptr(out), B, stream())
+    return out
+
+
+def greedy_accept(root_token: torch.Tensor, flat_ids: torch.Tensor, tree_indices: torch.Tensor,
+                  retrieve: torch.Tensor, target_argmax: torch.Tensor, prev_len: Optional[torch.Tensor],
+                  B: int = 1, want_debug: bool = False):
+    """result [B,4] int64 = {best_path, accept_length, next_token, new_len}."""
+    n_nodes = tree_indices.numel()
+    P_, W = retrieve.shape
+    dev = flat_ids.device
+    flat = flat_ids.reshape(B, -1)
+    result = torch.empty((B, 4), dtype=torch.int64, device=dev)
+    tok = cart = acc = None
+    if want_debug:
+        tok = torch.empty((B, n_nodes), dtype=torch.int64, device=dev)
+        cart = torch.empty((B, P_, W), dtype=torch.int64, device=dev)
+        acc = torch.empty((B, P_), dtype=torch.int32, device=dev)
+    call("eagle_greedy_accept", ptr(root_token), ptr(flat), flat.stride(0), ptr(tree_indices), n_nodes,
+         ptr(retrieve), P_, W, ptr(target_argmax), ptr(prev_len), ptr(tok), ptr(cart), ptr(acc), ptr(result), B, stream())
+    return (result, tok, cart, acc) if want_debug else result
+
+
+def kv_compact(cache: torch.Tensor, B: int, inner: int, retrieve: torch.Tensor, result: torch.Tensor,
+               prev_len: torch.Tensor, err_flag: Optional[torch.Tensor] = None) -> None:
+    """cache [..., cap, hd] contiguous with the leading dims flattening to (outer, B, inner)."""
+    _chk(cache, "cache")
+    if not cache.is_contiguous():
+        raise ValueError("kv_compact: cache must be contiguous")
+    cap, hd = cache.shape[-2], cache.shape[-1]
+    n_slabs = cache.numel() // (cap * hd)
+    call("eagle_kv_compact_bf16", ptr(cache), n_slabs, cap * hd, hd, B, inner, ptr(retrieve), retrieve.shape[1],
+         ptr(result), ptr(prev_len), cap, ptr(err_flag), stream())
+
+
+def gather_accepted(src: torch.Tensor, retrieve: torch.Tensor, result: torch.Tensor, B: int = 1) -> torch.Tensor:
+    _chk(src, "src")
+    n_nodes, D = src.shape[-2], src.shape[-1]
+    W = retrieve.shape[1]
+    out = torch.empty((B, W, D), dtype=BF16, device=src.device)
+    call("eagle_gather_accepted_bf16", ptr(src), n_nodes, D, ptr(retrieve), W, ptr(result), ptr(out), B, stream())
+    return out
+
+
+# ------------------------------------------------------------------ loss
+def ce_stat_bytes() -> int:
+    return query("eagle_ce_stat_bytes")
+
+
+def ce_partial(t_logits, o_logits, v0: int = 0, predict=None, target=None):
+    _chk(t_logits, "t_logits"), _chk(o_logits, "o_logits")
+    N, V = t_logits.shape
+    if t_logits.stride() != o_logits.stride() or t_logits.stride(1) != 1:
+        raise ValueError("logit tensors must share one row-major layout")
+    D = predict.shape[-1] if predict is not None else 0
+    stats = torch.empty((N, ce_stat_bytes() // 4), dtype=torch.float32, device=t_logits.device)
+    call("eagle_ce_partial_bf16", ptr(t_logits), ptr(o_logits), t_logits.stride(0), N, V, v0,
+         ptr(predict), ptr(target), D, ptr(stats), stream())
+    return stats
+
+
+def ce_combine(stats: torch.Tensor, mask: Optional[torch.Tensor]):
+    """stats [R,N,8] or [N,8] -> (sums[4], lse_t[N], lse_o[N], rows[N,4])."""
+    if stats.dim() == 2:
+        stats = stats[None]
+    R, N = stats.shape[0], stats.shape[1]
+    dev = stats.device
+    lse_t = torch.empty(N, dtype=torch.float32, device=dev)
+    lse_o = torch.empty(N, dtype=torch.float32, device=dev)
+    rows = torch.empty((N, 4), dtype=torch.float32, device=dev)
+    sums = torch.empty(4, dtype=torch.float32, device=dev)
+    call("eagle_ce_combine", ptr(stats.contiguous()), R, N, ptr(mask), ptr(lse_t), ptr(lse_o), ptr(rows), ptr(sums), stream())
+    return sums, lse_t, lse_o, rows
+
+
+def ce_smoothl1_bwd(t_logits, o_logits, lse_t, lse_o, mask, g_p: float, g_v: float, predict=None, target=None,
+                    in_place: bool = False):
+    N, V = t_logits.shape
+    dlog = o_logits if in_place else torch.empty_like(o_logits)
+    dpred = torch.empty_like(predict) if predict is not None else None
+    D = predict.shape[-1] if predict is not None else 0
+    call("eagle_ce_smoothl1_bwd_bf16", ptr(t_logits), ptr(o_logits), t_logits.stride(0), N, V, ptr(lse_t), ptr(lse_o),
+         ptr(mask), float(g_p), float(g_v), ptr(dlog), dlog.stride(0), ptr(predict), ptr(target), D, ptr(dpred), stream())
+    return dlog, dpred
+
+
+def rope_tables(head_dim: int, n_pos: int, base: float = 10000.0, device=None):
+    """bf16 cos/sin tables [n_pos, hd] as LlamaRotaryEmbedding builds them (eagle/llama2.py:70-93:
+    fp32 angles, half-split layout, cast to the activation dtype on use :100-102).  Built on the
+    host in fp32 so the values do not depend on the device's transcendental rounding."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    t = torch.arange(n_pos, dtype=torch.float32)
+    fr = torch.outer(t, inv_freq)
+    ang = torch.cat((fr, fr), dim=-1)
+    return ang.cos().to(BF16).to(device), ang.sin().to(BF16).to(device)

@@ -1,0 +1,135 @@
+/* eagle_hip.h -- C ABI of libeagle_hip.so: MI355X (gfx950) kernels for the EAGLE-1 draft/verify
+ * hot path and the draft-head training loss.
+ *
+ * The reference (vladislavkruglikov/eagle) has no native layer: its hot path is PyTorch eager
+ * code in eagle/llama2.py and eagle/train.py.  Each entry point below replaces the eager ops at
+ * the cited reference lines; the Python host (eagle_amd/) binds them with ctypes and passes raw
+ * device pointers, sizes and the current HIP stream.  No torch types cross this boundary.
+ *
+ * Conventions: every function returns 0 on success, EAGLE_ERR_SHAPE (1) when the operand shapes
+ * are outside what the kernel and its grid assume, EAGLE_ERR_LAUNCH (2) when the HIP launch
+ * failed, EAGLE_ERR_ARG (3) on null pointers / bad enums.  No exceptions cross the boundary.
+ * All "bf16" buffers are raw bfloat16 bits; all pointers are device pointers; launches are
+ * asynchronous on `stream`.  Nothing here allocates or synchronises.
+ */
+#ifndef EAGLE_HIP_H
+#define EAGLE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* eagle_stream_t; /* == hipStream_t */
+
+#define EAGLE_EPI_LINEAR 0
+#define EAGLE_EPI_SILU_MUL 1
+
+/* out[M,N] = epilogue(x[M,K] . W[N,K]^T), weight-streaming kernel for M <= 64 rows per weight
+ * pass (larger M loops).  x row m = cat(x0[idx0 ? idx0[m] : m][0:K0], x1[idx1 ? idx1[m] : m][0:K-K0])
+ * (x1 may be NULL: then K0 is ignored).  EPI_LINEAR: (+bias[N]) then (+res[M,N]), each rounded to
+ * bf16 like the eager ops.  EPI_SILU_MUL: out = silu(x.W^T) * (x.W2^T).
+ * Replaces nn.Linear at draft time: fc(cat(embed_tokens(ids), hidden)) eagle/llama2.py:515,:542;
+ * q/k/v/o_proj :222-224,:280; LlamaMLP :317; residual adds :385,:391; and the frozen lm_head
+ * eagle/train.py:215-228 applied to draft rows. Requires K % 32 == 0, K0 % 32 == 0. */
+int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int K0,
+                           const void* x1, const int64_t* idx1, int64_t ld1,
+                           const void* W, const void* W2, const void* bias,
+                           const void* res, int64_t ldr, void* out, int64_t ldo,
+                           int M, int N, int K, int epi, eagle_stream_t stream);
+
+/* y = w * bf16(x * rsqrt(mean(x^2) + eps)); optional rstd_out[N] (fp32) for the backward.
+ * Replaces LlamaRMSNorm.forward, eagle/llama2.py:330-335. D % 8 == 0, D <= 8192. */
+int eagle_rmsnorm_fwd_bf16(const void* x, const void* w, void* y, float* rstd_out, int N, int D,
+                           float eps, eagle_stream_t stream);
+/* Backward of the above (autograd of eagle/llama2.py:330-335): dx[N,D] bf16, dw[D] fp32
+ * (accumulate_dw != 0: dw += ...).  workspace: eagle_rmsnorm_bwd_workspace_bytes(N, D). */
+int64_t eagle_rmsnorm_bwd_workspace_bytes(int N, int D);
+int eagle_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const float* rstd, void* dx,
+                           float* dw, int accumulate_dw, void* workspace, int N, int D,
+                           eagle_stream_t stream);
+
+/* Tree-masked decode attention fused with RoPE and the KV-cache append, M <= 16 query rows per
+ * request.  qkv [B*rows_per_req, (H+2*HK)*hd] (fused q|k|v projection output; request b's query m
+ * is row b*rows_per_req + row_off + m, so longer inputs are processed in 16-row chunks),
+ * position_ids [B*rows_per_req],
+ * cos/sin tables [n_pos, hd] bf16 (the reference's cached tables cast to bf16),
+ * kcache/vcache [B, HK, cap, hd] (element stride between requests = cache_batch_stride),
+ * past_len [B] (device int32) + past_off = rows already in the cache; the M new roped K rows and
+ * V rows are appended at [past, past+M).  tree_mask [M,T] bytes (0 = masked) overlays the last T
+ * key columns (tree_mask_batch_stride 0 = shared by all requests); pad_mask [B, >= past+M] bytes
+ * (0 = padded key) or NULL; causal != 0 adds the causal mask when M > 1.  out [B*rows_per_req, H*hd].
+ * max_kv >= max_b(past+M) sizes the LDS score buffer (eagle_attn_decode_lds_bytes(max_kv) <= 160 KiB).
+ * Device-side violations (past+M > cap or > max_kv) set *err_flag = 1 and skip the request.
+ * Replaces LlamaAttention.forward after the projections, eagle/llama2.py:226-273, with the mask
+ * semantics of _prepare_decoder_attention_mask :460-491 (tree overlay :482-488). */
+int64_t eagle_attn_decode_lds_bytes(int max_kv);
+int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const int64_t* position_ids,
+                              const void* cos_table, const void* sin_table, int n_pos,
+                              void* kcache, void* vcache, int64_t cache_batch_stride, int cap,
+                              const int32_t* past_len, int past_off,
+                              const uint8_t* tree_mask, int T, int64_t tree_mask_batch_stride,
+                              const uint8_t* pad_mask, int64_t pad_mask_stride,
+                              void* out, int64_t ld_out, int* err_flag,
+                              int B, int M, int H, int HK, int hd, int max_kv, int causal,
+                              int rows_per_req, int row_off, eagle_stream_t stream);
+
+/* Per-row top-k over the vocabulary; order = value descending then index ascending (a stable
+ * descending sort; -0.0 == +0.0; NaN largest).  dtype 0 = bf16 logits, 1 = fp32.  out_idx
+ * [rows,k] int64, out_val [rows,k] (logits dtype, may be NULL), k <= 16.
+ * workspace: eagle_topk_workspace_bytes(rows, V, k).
+ * Replaces torch.topk(last_headout, top_k) of the expansion loop (top_k = 10, eagle/llama2.py:11;
+ * SURVEY.md a20) and, with k = 1, torch.max(..., 2) index selection (eagle/train.py:115-116). */
+int64_t eagle_topk_workspace_bytes(int rows, int V, int k);
+int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V, int k,
+                     int64_t* out_idx, void* out_val, void* workspace, eagle_stream_t stream);
+
+/* Static-tree kernels (Llama2Model.init_tree / tree_mask hooks,
+ * eagle/llama2.py:453-458 -- the algorithm itself is the upstream EAGLE-1 one). */
+/* out_ids[b][j] = flat_ids[b][tree_idx[j]]: draft tokens of one expansion step. */
+int eagle_tree_gather_ids(const int64_t* flat_ids, int64_t flat_batch_stride, const int64_t* tree_idx,
+                          int n, int64_t* out_ids, int B, eagle_stream_t stream);
+/* Greedy acceptance along the tree's root->leaf paths.  result[b] = {best_path, accept_length,
+ * next_token, prev_len[b] + accept_length + 1}; optional tree_tok_out [B,n_nodes],
+ * cart_out [B,P,W], accept_out [B,P]. */
+int eagle_greedy_accept(const int64_t* root_token, const int64_t* flat_ids, int64_t flat_batch_stride,
+                        const int64_t* tree_indices, int n_nodes, const int64_t* retrieve, int P, int W,
+                        const int64_t* target_argmax, const int32_t* prev_len, int64_t* tree_tok_out,
+                        int64_t* cart_out, int32_t* accept_out, int64_t* result, int B,
+                        eagle_stream_t stream);
+/* In-place compaction of the accepted path's KV rows: cache viewed as [n_slabs][cap][row_elems]
+ * with slab = (outer*B + b)*inner + i; rows prev_len[b] + retrieve[best][j] -> prev_len[b] + j. */
+int eagle_kv_compact_bf16(void* cache, int64_t n_slabs, int64_t slab_stride, int row_elems, int B,
+                          int inner, const int64_t* retrieve, int W, const int64_t* result,
+                          const int32_t* prev_len, int cap, int* err_flag, eagle_stream_t stream);
+/* out[b][j] = src[b][retrieve[best_b][j]] for j <= accept_length_b (zeros after). */
+int eagle_gather_accepted_bf16(const void* src, int n_nodes, int D, const int64_t* retrieve, int W,
+                               const int64_t* result, void* out, int B, eagle_stream_t stream);
+
+/* Fused soft-label CE + smooth-L1 + agreement at the logits level.
+ * Replaces eagle/train.py:108-123 (== eagle/train_tp.py:90-105).
+ * ce_partial: one vocab shard [N, V] (columns v0..v0+V of the full vocabulary) -> stats [N]
+ *   records of eagle_ce_stat_bytes() bytes; predict/target [N,D] optional (smooth-L1 row means).
+ * ce_combine: merges R shards' stats [R,N] -> lse_t/lse_o [N], row_out [N,4] =
+ *   {ploss_row, vloss_row, agree, 0}, sums[4] = {sum m*ploss, sum m*vloss, sum m*agree, sum m}.
+ * bwd: dlogits = mask*g_p*(softmax(o)-softmax(t)) (may alias o_logits),
+ *   dpredict = mask*g_v*clamp(predict-target,-1,1)/D. */
+int eagle_ce_stat_bytes(void);
+int eagle_ce_partial_bf16(const void* t_logits, const void* o_logits, int64_t ld, int N, int V, int v0,
+                          const void* predict, const void* target, int D, void* stats,
+                          eagle_stream_t stream);
+int eagle_ce_combine(const void* stats, int R, int N, const float* mask, float* lse_t, float* lse_o,
+                     float* row_out, float* sums, eagle_stream_t stream);
+int eagle_fused_ce_smoothl1_fwd_bf16(const void* t_logits, const void* o_logits, int64_t ld, int N, int V,
+                                     const void* predict, const void* target, int D, const float* mask,
+                                     void* stats_ws, float* lse_t, float* lse_o, float* row_out,
+                                     float* sums, eagle_stream_t stream);
+int eagle_ce_smoothl1_bwd_bf16(const void* t_logits, const void* o_logits, int64_t ld, int N, int V,
+                               const float* lse_t, const float* lse_o, const float* mask, float g_p,
+                               float g_v, void* dlogits, int64_t ldd, const void* predict,
+                               const void* target, int D, void* dpredict, eagle_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

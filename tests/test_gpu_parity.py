@@ -1,0 +1,341 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs and against the golden fixtures generated from the reference.
+
+Bars (BASELINE.json north_star): bit-exact for top-k ids (tie-break value desc / index asc),
+tree indices, masks, acceptance lengths and compaction; bf16 rtol 1e-2 for hidden states,
+logits and loss."""
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import draft_model as dm
+from oracle import loss as ol
+from oracle import tree as ot
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def close(a, b, rtol=1e-2, atol=None, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    scale = float(b.abs().mean()) + 1e-12
+    atol = atol if atol is not None else 2e-2 * scale
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = int((err > tol).sum())
+    # bf16 outputs can legitimately flip one ulp (2^-8 relative): allow a few stragglers at 2x
+    assert bad <= 1e-3 * a.numel() and float((err / (tol)).max()) < 3.0, \
+        f"{what}: {bad}/{a.numel()} outside tol, max err {float(err.max()):.4g} (scale {scale:.4g})"
+
+
+# ------------------------------------------------------------------ skinny GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (4, 4096, 4096), (8, 4096, 8192), (3, 11008, 4096), (16, 4096, 11008),
+                                   (7, 100, 64), (5, 64, 128), (2, 32000, 4096), (20, 512, 4096), (40, 256, 96), (70, 128, 256)])
+def test_gemm_skinny_linear(M, N, K):
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(M * 131 + N + K)
+    x = (torch.randn(M, K, generator=g)).to(BF)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    b = torch.randn(N, generator=g).to(BF)
+    r = torch.randn(M, N, generator=g).to(BF)
+    ref = x.float() @ W.float().t()
+    y = ops.linear_skinny(x.to(dev()), W.to(dev()))
+    close(y, ref, what="plain")
+    y = ops.linear_skinny(x.to(dev()), W.to(dev()), bias=b.to(dev()), res=r.to(dev()))
+    ref2 = (ref + b.float()).to(BF).float() + r.float()
+    close(y, ref2, what="bias+res")
+
+
+@pytest.mark.parametrize("M,I,K", [(1, 11008, 4096), (8, 12288, 4096), (4, 128, 64), (24, 256, 128)])
+def test_gemm_skinny_silu_mul(M, I, K):
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(7 + M)
+    x = torch.randn(M, K, generator=g).to(BF)
+    Wg = (torch.randn(I, K, generator=g) / K ** 0.5).to(BF)
+    Wu = (torch.randn(I, K, generator=g) / K ** 0.5).to(BF)
+    gt = (x.float() @ Wg.float().t()).to(BF)
+    up = (x.float() @ Wu.float().t()).to(BF)
+    ref = torch.nn.functional.silu(gt) * up
+    y = ops.linear_skinny(x.to(dev()), Wg.to(dev()), W2=Wu.to(dev()))
+    close(y, ref, what="silu*up")
+
+
+def test_gemm_skinny_gather_concat():
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(11)
+    V, D, M = 1000, 256, 6
+    emb = torch.randn(V, D, generator=g).to(BF)
+    hid = torch.randn(9, D, generator=g).to(BF)
+    W = (torch.randn(D, 2 * D, generator=g) / (2 * D) ** 0.5).to(BF)
+    bias = torch.randn(D, generator=g).to(BF)
+    ids = torch.randint(0, V, (M,), generator=g)
+    prow = torch.tensor([0, 0, 3, 8, 8, 1])
+    ref = torch.cat([emb[ids], hid[prow]], -1).float() @ W.float().t() + bias.float()
+    y = ops.linear_skinny(emb.to(dev()), W.to(dev()), bias=bias.to(dev()), idx0=ids.to(dev()), x1=hid.to(dev()),
+                          idx1=prow.to(dev()), M=M)
+    close(y, ref, what="gather+concat")
+
+
+def test_gemm_skinny_rejects_bad_shapes():
+    from eagle_amd import ops
+    from eagle_amd._hip import HipKernelError
+    x = torch.zeros(2, 40, dtype=BF, device=dev())
+    W = torch.zeros(16, 40, dtype=BF, device=dev())
+    with pytest.raises(HipKernelError):
+        ops.linear_skinny(x, W)  # K % 32 != 0
+
+
+# ------------------------------------------------------------------ rmsnorm
+@pytest.mark.parametrize("N,D", [(1, 4096), (8, 4096), (5, 64), (3, 8192)])
+def test_rmsnorm(N, D):
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(N + D)
+    x = (torch.randn(N, D, generator=g) * 3).to(BF)
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(BF)
+    ref = dm.rmsnorm(x, w, 1e-6)
+    y = ops.rmsnorm(x.to(dev()), w.to(dev()), 1e-6)
+    close(y, ref, rtol=8e-3, what="rmsnorm")
+
+
+# ------------------------------------------------------------------ top-k (bit-exact ids)
+@pytest.mark.parametrize("rows,V", [(1, 32000), (8, 32000), (4, 151936), (3, 100), (2, 4097), (16, 9000)])
+@pytest.mark.parametrize("dtype", [BF, torch.float32])
+def test_topk_bit_exact(rows, V, dtype):
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(rows * 7 + V)
+    x = (torch.randn(rows, V, generator=g) * 4).to(dtype)  # bf16 logits over a big vocab are full of ties
+    ev, ei = ot.stable_topk(x, 10)
+    v, i = ops.topk(x.to(dev()), 10)
+    assert torch.equal(i.cpu(), ei), "top-k ids differ from the stable-sort oracle"
+    assert torch.equal(v.cpu(), ev)
+    assert torch.equal(ops.first_argmax(x.to(dev())).cpu(), ot.first_argmax(x))
+
+
+def test_topk_tie_and_special_values():
+    from eagle_amd import ops
+    x = torch.zeros(4, 5000, dtype=BF)
+    x[0, [4999, 7, 4096, 4095, 8]] = 3.0          # ties across chunk boundary -> lowest index first
+    x[1] = -1.0; x[1, [10, 20]] = torch.tensor([0.0, -0.0], dtype=BF)  # -0.0 == +0.0
+    x[2, 100] = float("inf"); x[2, 50] = float("nan"); x[2, 4500] = float("nan")  # NaN above +inf
+    x[3] = torch.arange(5000, dtype=torch.float32).to(BF) * -1.0    # descending ramp with bf16 plateaus
+    ev, ei = ot.stable_topk(x, 10)
+    v, i = ops.topk(x.to(dev()), 10)
+    assert torch.equal(i.cpu(), ei)
+    assert i[0, :5].tolist() == [7, 8, 4095, 4096, 4999]
+    assert i[1, :2].tolist() == [10, 20]
+    assert i[2, :3].tolist() == [50, 4500, 100]
+
+
+# ------------------------------------------------------------------ draft model vs reference fixtures
+def _model(dims: dm.DraftDims, weights, n_layers=1):
+    from eagle_amd.config import DraftConfig
+    from eagle_amd.llama2 import Llama2Model
+    cfg = DraftConfig(hidden_size=dims.hidden, intermediate_size=dims.inter, num_attention_heads=dims.heads,
+                      num_key_value_heads=dims.kv_heads, vocab_size=dims.vocab)
+    m = Llama2Model(cfg)
+    m.load_state_dict(weights, strict=True)
+    return m.to(BF).to(dev()).eval()
+
+
+def test_model_g1_tiny_fixture(golden_dir):
+    fx = load_file(os.path.join(golden_dir, "g1_tiny_bf16.safetensors"))
+    dims = dm.DraftDims(hidden=64, inter=128, heads=4, kv_heads=4, vocab=100)
+    w = {k[2:]: v for k, v in fx.items() if k.startswith("w.")}
+    m = _model(dims, w)
+    d = dev()
+    with torch.no_grad():
+        close(m(fx["a.hidden"].to(d), fx["a.ids"].to(d)), fx["a.out"], what="a.out")
+        o, kv = m(fx["a.hidden"].to(d), fx["a.ids"].to(d), use_cache=True)
+        assert tuple(kv[0][0].shape) == tuple(fx["b.k"].shape)
+        close(o, fx["b.out"], what="b.out"); close(kv[0][0], fx["b.k"], what="b.k"); close(kv[0][1], fx["b.v"], what="b.v")
+        kv_b = ((kv[0][0].clone(), kv[0][1].clone()),)   # foreign tensors: exercises the copy-in path
+        o2, kv2 = m(fx["c.hidden"].to(d), fx["c.ids"].to(d), past_key_values=kv, use_cache=True)
+        close(o2, fx["c.out"], what="c.out"); close(kv2[0][0], fx["c.k"], what="c.k"); close(kv2[0][1], fx["c.v"], what="c.v")
+        o3, kv3 = m(fx["d.hidden"].to(d), fx["d.ids"].to(d), past_key_values=kv2, use_cache=True)
+        close(o3, fx["d.out"], what="d.out (q=1)"); close(kv3[0][0], fx["d.k"], what="d.k")
+        tb = ot.generate_tree_buffers()
+        past = kv_b
+        for s in range(2):
+            m.tree_mask = tb.step_attn_mask[s].to(d)
+            od, past = m(fx[f"e{s}.hidden"].to(d), fx[f"e{s}.ids"].to(d), past_key_values=past,
+                         position_ids=fx[f"e{s}.pos"].to(d), use_cache=True)
+            close(od, fx[f"e{s}.out"], what=f"e{s}.out (tree step)")
+            close(past[0][0], fx[f"e{s}.k"], what=f"e{s}.k")
+        m.reset()
+        of = m(fx["f.hidden"].to(d), fx["f.ids"].to(d), attention_mask=fx["f.mask"].bool().to(d))
+        close(of, fx["f.out"], what="f.out (padded batch)")
+
+
+def test_model_g2_real_dims_fixture(golden_dir):
+    fx = load_file(os.path.join(golden_dir, "g2_real_bf16.safetensors"))
+    dims = dm.DraftDims()
+    m = _model(dims, dm.init_weights(dims, seed=1234))
+    d = dev()
+    with torch.no_grad():
+        o, kv = m(fx["hidden"].to(d), fx["ids"].to(d), use_cache=True)
+        close(o, fx["out"], what="out"); close(kv[0][0], fx["k"], what="k"); close(kv[0][1], fx["v"], what="v")
+        tb = ot.generate_tree_buffers()
+        m.tree_mask = tb.step_attn_mask[0].to(d)
+        o2, _ = m(fx["t.hidden"].to(d), fx["t.ids"].to(d), past_key_values=kv, position_ids=fx["t.pos"].to(d), use_cache=True)
+        close(o2, fx["t.out"], what="tree step out")
+
+
+def test_model_long_prefill_and_decode_vs_oracle():
+    """q_len > 16 (chunked attention), then single-row decode, against the oracle in bf16."""
+    dims = dm.DraftDims(hidden=256, inter=512, heads=2, kv_heads=2, vocab=500)  # head_dim 128
+    w = dm.init_weights(dims, seed=3, std=0.05)
+    m = _model(dims, w)
+    wb = {k: v.to(BF) for k, v in w.items()}
+    g = torch.Generator().manual_seed(9)
+    h = torch.randn(2, 37, 256, generator=g).to(BF)
+    ids = torch.randint(0, 500, (2, 37), generator=g)
+    d = dev()
+    with torch.no_grad():
+        ro, rkv = dm.forward(wb, dims, h, ids, use_cache=True)
+        o, kv = m(h.to(d), ids.to(d), use_cache=True)
+        close(o, ro, what="prefill out"); close(kv[0][0], rkv[0][0], what="prefill k")
+        h1 = torch.randn(2, 1, 256, generator=g).to(BF)
+        i1 = torch.randint(0, 500, (2, 1), generator=g)
+        ro1, _ = dm.forward(wb, dims, h1, i1, past_key_values=rkv, use_cache=True)
+        o1, _ = m(h1.to(d), i1.to(d), past_key_values=kv, use_cache=True)
+        close(o1, ro1, what="decode out")
+
+
+# ------------------------------------------------------------------ tree kernels (bit-exact)
+def test_greedy_accept_and_compaction_bit_exact():
+    from eagle_amd import ops
+    from eagle_amd.tree import TreeBuffers
+    d = dev()
+    for expand in ("wchild", "all"):
+        tb_o = ot.generate_tree_buffers(expand=expand)
+        tb = TreeBuffers(expand=expand, device=d)
+        g = torch.Generator().manual_seed(17)
+        n_rows = 1 + sum(len(s) for s in tb_o.step_nodes)
+        B = 6
+        flat = torch.randint(0, 50, (B, n_rows, 10), generator=g)
+        root = torch.randint(0, 50, (B,), generator=g)
+        tgt = torch.randint(0, 50, (B, tb_o.n_nodes), generator=g)
+        prev = torch.tensor([5, 9, 0, 3, 7, 11], dtype=torch.int32)
+        # plant agreement so that several depths get accepted
+        for b in range(B):
+            tok, _ = ot.tree_candidates(int(root[b]), flat[b], tb_o)
+            node = 0
+            for _ in range(b):  # request b accepts up to b steps down the first-child chain
+                kids = [i for i in range(tb_o.n_nodes) if tb_o.parent[i] == node]
+                if not kids:
+                    break
+                tgt[b, node] = tok[kids[-1] if b % 2 else kids[0]]
+                node = kids[-1] if b % 2 else kids[0]
+        res, tok_g, cart_g, acc_g = ops.greedy_accept(root.to(d), flat.to(d), tb.tree_indices, tb.retrieve_indices,
+                                                      tgt.to(d), prev.to(d), B=B, want_debug=True)
+        hidden = torch.randn(B, tb_o.n_nodes, 64, generator=g).to(BF)
+        cap = 48
+        kvc = torch.randn(3, B, 2, cap, 16, generator=g).to(BF)  # [outer, B, inner, cap, hd]
+        kv_g = kvc.to(d).clone()
+        ops.kv_compact(kv_g, B, 2, tb.retrieve_indices, res, prev.to(d))
+        acc_h = ops.gather_accepted(hidden.to(d), tb.retrieve_indices, res, B=B)
+        for b in range(B):
+            tok, cart = ot.tree_candidates(int(root[b]), flat[b], tb_o)
+            best, alen, nxt, acc = ot.greedy_accept(cart, tgt[b], tb_o)
+            assert res[b].tolist() == [best, alen, nxt, int(prev[b]) + alen + 1]
+            assert torch.equal(tok_g[b].cpu(), tok) and torch.equal(cart_g[b].cpu(), cart)
+            assert acc_g[b].tolist() == acc.tolist()
+            ref_kv = kvc[:, b].clone()
+            _, ref_h = ot.compact([ref_kv], hidden[b:b + 1], tb_o, best, alen, int(prev[b]))
+            assert torch.equal(kv_g[:, b].cpu(), ref_kv)
+            assert torch.equal(acc_h[b, : alen + 1].cpu(), ref_h[0])
+            assert float(acc_h[b, alen + 1:].abs().sum()) == 0.0
+        assert sorted(set(res[:, 1].tolist())) != [0], "test inputs should accept something"
+
+
+def test_tree_gather_ids():
+    from eagle_amd import ops
+    from eagle_amd.tree import TreeBuffers
+    d = dev()
+    tb = TreeBuffers(device=d)
+    flat = torch.arange(2 * 40).view(2, 40) * 3
+    out = ops.tree_gather_ids(flat.to(d), tb.steps[1].tree_indices, B=2)
+    assert out.cpu().tolist() == [[0, 3, 6, 30], [120, 123, 126, 150]]
+
+
+# ------------------------------------------------------------------ fused loss
+@pytest.mark.parametrize("N,V,D", [(8, 1000, 32), (6, 4099, 64), (4, 151936, 4096), (16, 32000, 4096)])
+def test_fused_loss_fwd_bwd(N, V, D):
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(N + V)
+    t = (torch.randn(N, V, generator=g) * 3).to(BF)
+    o = (t.float() + torch.randn(N, V, generator=g) * 1.5).to(BF)
+    o[0] = t[0]  # identical rows -> agreement and equal argmax with ties resolved the same way
+    predict = torch.randn(N, D, generator=g).to(BF)
+    target = (predict.float() + 0.8 * torch.randn(N, D, generator=g)).to(BF)
+    mask = (torch.rand(N, generator=g) < 0.7).float()
+    mask[0] = 1
+    ex = ol.exact_loss_from_logits(t, o, predict, target, mask)
+    d = dev()
+    stats = ops.ce_partial(t.to(d), o.to(d), 0, predict.to(d), target.to(d))
+    sums, lse_t, lse_o, rows = ops.ce_combine(stats, mask.to(d))
+    # loss: bf16 tolerance rtol 1e-2 (north_star); the fp32-accumulating kernel is far inside it
+    assert abs(float(sums[0]) - float(ex["ploss"])) <= 1e-3 * abs(float(ex["ploss"])) + 1e-4
+    assert abs(float(sums[1]) - float(ex["vloss"])) <= 1e-3 * abs(float(ex["vloss"])) + 1e-5
+    assert int(sums[2]) == int(ex["correct"]) and int(sums[3]) == int(mask.sum())
+    close(lse_t, ex["lse_t"], rtol=1e-4, atol=1e-3, what="lse_t"); close(lse_o, ex["lse_o"], rtol=1e-4, atol=1e-3, what="lse_o")
+    close(rows[:, 0], ex["ploss_row"], rtol=2e-3, atol=2e-3, what="ploss_row")
+    # argmax ids are exact (first max index)
+    st = stats.view(torch.int32)
+    assert torch.equal(st[:, 5].cpu().long(), ex["t_tok"]) and torch.equal(st[:, 6].cpu().long(), ex["o_tok"])
+    g_p, g_v = 0.1 / max(1.0, float(mask.sum())), 1.0 / max(1.0, float(mask.sum()))
+    dlog, dpv = ops.ce_smoothl1_bwd(t.to(d), o.to(d), lse_t, lse_o, mask.to(d), g_p, g_v, predict.to(d), target.to(d))
+    rl, rv = ol.exact_grads_from_logits(t, o, predict, target, mask, g_p, g_v)
+    close(dlog, rl, rtol=1e-2, atol=float(rl.abs().max()) * 2e-3, what="dlogits")
+    close(dpv, rv, rtol=1e-2, atol=float(rv.abs().max()) * 4e-3, what="dpredict(smooth-l1)")
+    # in-place variant writes the same values over the out-logits buffer
+    o_d = o.to(d).clone()
+    dlog2, _ = ops.ce_smoothl1_bwd(t.to(d), o_d, lse_t, lse_o, mask.to(d), g_p, g_v, in_place=True)
+    assert dlog2.data_ptr() == o_d.data_ptr() and torch.equal(dlog2, dlog)
+
+
+def test_loss_matches_reference_eager_fixture(golden_dir):
+    """Against the fixture made with the reference's eager op order in bf16 (rtol 1e-2)."""
+    from eagle_amd import ops
+    fx = load_file(os.path.join(golden_dir, "g3_loss_bf16.safetensors"))
+    d = dev()
+    for c in ("s", "m"):
+        t = fx[f"{c}.t_logits"].reshape(-1, fx[f"{c}.t_logits"].shape[-1])
+        o = fx[f"{c}.o_logits"].reshape(-1, t.shape[-1])
+        D = fx[f"{c}.predict"].shape[-1]
+        mask = fx[f"{c}.mask"].reshape(-1).float()
+        stats = ops.ce_partial(t.to(d), o.to(d), 0, fx[f"{c}.predict"].reshape(-1, D).to(d), fx[f"{c}.target"].reshape(-1, D).to(d))
+        sums, lse_t, lse_o, _ = ops.ce_combine(stats, mask.to(d))
+        loss = 1.0 * float(sums[1]) + 0.1 * float(sums[0])
+        assert abs(loss - float(fx[f"{c}.loss"])) <= 1e-2 * abs(float(fx[f"{c}.loss"]))
+        assert abs(float(sums[0]) - float(fx[f"{c}.ploss"])) <= 1e-2 * abs(float(fx[f"{c}.ploss"]))
+        dlog, dpv = ops.ce_smoothl1_bwd(t.to(d), o.to(d), lse_t, lse_o, mask.to(d), 0.1, 1.0,
+                                        fx[f"{c}.predict"].reshape(-1, D).to(d), fx[f"{c}.target"].reshape(-1, D).to(d))
+        ref = fx[f"{c}.dlogits"].reshape(-1, t.shape[-1])
+        close(dlog, ref, rtol=2e-2, atol=float(ref.float().abs().max()) * 8e-3, what="dlogits vs eager bf16")
+
+
+def test_sharded_ce_partials_combine_exactly_like_unsharded():
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(5)
+    N, V, R = 12, 8 * 1000, 8
+    t = (torch.randn(N, V, generator=g) * 3).to(BF)
+    o = (torch.randn(N, V, generator=g) * 3).to(BF)
+    t[3, [10, 5000]] = 30.0  # a tie that spans shards: lowest global index must win
+    d = dev()
+    full = ops.ce_partial(t.to(d), o.to(d), 0)
+    s1, lt1, lo1, r1 = ops.ce_combine(full, None)
+    Vs = V // R
+    parts = torch.stack([ops.ce_partial(t[:, r * Vs:(r + 1) * Vs].to(d).contiguous(), o[:, r * Vs:(r + 1) * Vs].to(d).contiguous(), r * Vs)
+                         for r in range(R)])
+    s2, lt2, lo2, r2 = ops.ce_combine(parts, None)
+    close(lt2, lt1, rtol=1e-5, atol=1e-4, what="lse_t sharded"); close(r2[:, 0], r1[:, 0], rtol=1e-4, atol=1e-3, what="ploss rows sharded")
+    assert torch.equal(r2[:, 2], r1[:, 2])
+    ex = ol.exact_loss_from_logits(t, o, torch.zeros(N, 8), torch.zeros(N, 8), torch.ones(N))
+    assert int(s2[2]) == int(ex["correct"])
