@@ -1,0 +1,299 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the EAGLE draft/verify hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload at N=1 (BASELINE.json configs[1]): EAGLE-1 draft head with Llama-2-7B dims
+(resources/eagle_config.json: D=4096, I=11008, 32 heads, V=32000), static 25-path tree
+(depth 5, top-k 10), greedy verification, batch 1, ~300-token synthetic prompt, random-init
+weights.  One bench "step" = one full draft/verify cycle:
+    verify (argmax of the verifier's logits at the 26 tree nodes, greedy acceptance, KV
+    compaction of a 32-layer verifier cache, accepted-hidden gather) + catch-up draft forward
+    + 4 tree-expansion forwards, each followed by lm_head and top-k(10).
+`value` = draft-tree (depth) steps per second = draft forwards (each with lm_head + top-k) per
+second, whole job.  The verifier forward itself is out of scope: its
+logits / hidden states are synthetic tensors already resident in HBM, generated in an untimed
+closed-loop recording pass with planted agreement so that acceptance lengths are non-trivial;
+the timed pass replays exactly that generation (and asserts it reproduces the same lengths).
+
+For N>1 every rank runs an independent replica (no data-path collective; "scaling": "weak").
+The JSON line also carries `roofline` (the lm_head weight-streaming GEMM, the dominant kernel),
+`cpu_baseline` (the CPU oracle on the host cores, bounded sample) and `train` (draft-head
+training tokens/s, DP over the N ranks with RCCL all-reduce) when that path is available.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--ctx", type=int, default=300)
+    ap.add_argument("--config", default="llama2_7b", choices=["llama2_7b", "qwen3_8b"])
+    ap.add_argument("--expand", default="wchild", choices=["wchild", "all"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--plant", type=float, default=0.8, help="probability that the synthetic verifier agrees with a drafted child")
+    return ap.parse_args()
+
+
+def make_model(cfg_name: str, dev, seed=0):
+    from eagle_amd.config import DraftConfig, LLAMA2_7B_DRAFT, QWEN3_8B_DRAFT
+    from eagle_amd.llama2 import Llama2Model
+
+    cfg = DraftConfig(**(LLAMA2_7B_DRAFT if cfg_name == "llama2_7b" else QWEN3_8B_DRAFT))
+    with torch.device("meta"):
+        model = Llama2Model(cfg)
+    model = model.to_empty(device=dev).to(torch.bfloat16)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("layernorm.weight"):
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16))
+        lm_head = (torch.randn((cfg.vocab_size, cfg.hidden_size), generator=g, device=dev, dtype=torch.float32) * 0.02).to(torch.bfloat16)
+    model.eval()
+    return cfg, model, lm_head
+
+
+class SyntheticVerifier:
+    """Stand-in for the out-of-scope verifier: per cycle a [n_nodes, V] logits tensor and a
+    [n_nodes, D] hidden tensor.  During recording it plants agreement with the drafted tree."""
+
+    def __init__(self, n_cycles, n_nodes, V, D, dev, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.logits = torch.randn((n_cycles, n_nodes, V), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        self.hidden = torch.randn((n_cycles, n_nodes, D), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+        self.cpu_gen = torch.Generator().manual_seed(seed + 1)
+
+    def plant(self, c, tree_tok, tb, prob):
+        node = 0
+        kids_of = {}
+        for i in range(1, tb.n_nodes):
+            kids_of.setdefault(tb.parent[i], []).append(i)
+        while node in kids_of and float(torch.rand(1, generator=self.cpu_gen)) < prob:
+            kids = kids_of[node]
+            kid = kids[int(torch.randint(0, len(kids), (1,), generator=self.cpu_gen))]
+            self.logits[c, node, int(tree_tok[kid])] = 60.0
+            node = kid
+
+
+def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, plant_prob, tgt_kv, graph=False, timed_from=0,
+               timed_n=0, sync=None):
+    """Closed-loop generation.  Returns (accept lengths list, elapsed seconds of the timed span)."""
+    dev = drafter.dev
+    B = drafter.B
+    ctx = prompt_hidden.shape[1]
+    drafter.prefill(prompt_hidden, prompt_tokens)
+    root = prompt_tokens[:, -1].clone()
+    prev_len = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+    cyc = torch.zeros(1, dtype=torch.int64, device=dev)
+    res_log = torch.zeros((n_cycles, B, 4), dtype=torch.int64, device=dev)
+
+    def one_cycle():
+        tl = ver.logits.index_select(0, cyc)           # [1, n_nodes, V]  (B == 1 per replica)
+        th = ver.hidden.index_select(0, cyc)
+        res = drafter.verify(root, tl, prev_len)
+        acc_h = drafter.compact(prev_len, tgt_kv, th, kv_inner=tgt_kv.shape[2] if tgt_kv is not None else 1)
+        res_log.index_copy_(0, cyc, res[None])
+        root.copy_(res[:, 2])
+        prev_len.copy_(res[:, 3])
+        cyc.add_(1)
+        drafter.draft(acc_h, drafter.next_ids, drafter.n_acc)
+
+    g = None
+    elapsed = 0.0
+    t0 = None
+    for c in range(n_cycles):
+        if record:
+            tok = torch.cat([root, drafter.flat_ids[0].reshape(-1)])[drafter.tb.tree_indices]
+            ver.plant(c, tok.cpu(), drafter.tb, plant_prob)
+        if c == timed_from and timed_n:
+            sync()
+            t0 = time.perf_counter()
+        if graph and not record:
+            if g is None and c >= 2:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    one_cycle()          # capture does not execute: replay below runs this cycle
+                g.replay()
+            elif g is not None:
+                g.replay()
+            else:
+                one_cycle()
+        else:
+            one_cycle()
+        if timed_n and c == timed_from + timed_n - 1:
+            sync()
+            elapsed = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    drafter.check_errors()
+    return res_log[:, 0, 1].cpu().tolist(), elapsed
+
+
+def roofline_lm_head(drafter, rows, iters=40):
+    """Dominant kernel: gemm_skinny_kernel<2,1,0> = the lm_head weight stream.  Algorithmic bytes
+    per launch = V*D*2 (weights) + rows*D*2 (x) + rows*V*2 (logits write); HIP events on the
+    launch stream around `iters` back-to-back launches."""
+    from eagle_amd import ops
+    W = drafter.lm_head
+    V, D = W.shape
+    x = torch.randn((rows, D), device=W.device, dtype=torch.float32).to(torch.bfloat16)
+    out = torch.empty((rows, V), device=W.device, dtype=torch.bfloat16)
+    for _ in range(5):
+        ops.linear_skinny(x, W, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.linear_skinny(x, W, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    nbytes = V * D * 2 + rows * D * 2 + rows * V * 2
+    return {"bound": "hbm", "kernel": "gemm_skinny_kernel<2,1,0> (lm_head, %d rows)" % rows,
+            "achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "bytes_per_launch": nbytes, "us_per_launch": sec * 1e6}
+
+
+def cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, expand, max_seconds=25.0):
+    """The CPU oracle (oracle/, 'port') on the same workload, bounded sample: prompt prefill +
+    expansion cycles until ~max_seconds.  Reported in the same unit as `value`."""
+    from oracle import draft_model as dm
+    from oracle import tree as ot
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    dims = dm.DraftDims(hidden=cfg.hidden_size, inter=cfg.intermediate_size, heads=cfg.num_attention_heads,
+                        kv_heads=cfg.num_key_value_heads, vocab=cfg.vocab_size)
+    w = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    head = lm_head.cpu()
+    tb = ot.generate_tree_buffers(expand=expand)
+
+    def draft(h, ids, past_key_values=None, position_ids=None, tree_mask=None, use_cache=True):
+        return dm.forward(w, dims, h, ids, past_key_values=past_key_values, position_ids=position_ids,
+                          tree_mask=tree_mask, use_cache=True)
+
+    hidden, tokens = prompt_hidden.cpu(), prompt_tokens.cpu()
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        ids, _, stable, _ = ot.topk_generate(draft, head, tb, hidden, tokens, None)   # prefill cycle (untimed warm-up)
+        n_fw, t0 = 0, time.perf_counter()
+        cycles = 0
+        while time.perf_counter() - t0 < max_seconds and cycles < 8:
+            n_acc = 1 + cycles % 3
+            acc_h = torch.randn(1, n_acc, dims.hidden, generator=g).to(torch.bfloat16)
+            tokens = torch.cat([tokens, torch.randint(0, dims.vocab, (1, n_acc), generator=g)], dim=1)
+            ids, _, stable, _ = ot.topk_generate(draft, head, tb, acc_h, tokens, stable)
+            n_fw += 1 + len(tb.step_nodes)
+            cycles += 1
+        dt = time.perf_counter() - t0
+    return {"value": n_fw / dt, "unit": "draft-tree steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{cycles} expansion cycles ({n_fw} draft forwards + lm_head + top-k) after a {hidden.shape[1]}-token prefill, "
+                      f"bf16 torch CPU oracle, batch 1, ctx~{hidden.shape[1]}"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    from eagle_amd.speculative import EagleDrafter
+
+    cfg, model, lm_head = make_model(a.config, dev, seed=0)
+    drafter = EagleDrafter(model, lm_head, expand=a.expand, batch=1, max_ctx=2048)
+    n_fw = 1 + len(drafter.tb.steps)
+    n_cycles = a.warmup + a.steps
+    if a.ctx + n_cycles * drafter.W > 2048:
+        raise SystemExit("ctx + cycles*W exceeds the 2048-token cache of this bench")
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    prompt_hidden = torch.randn((1, a.ctx, cfg.hidden_size), generator=g, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    prompt_tokens = torch.randint(0, cfg.vocab_size, (1, a.ctx + 1), generator=g, device=dev)
+    ver = SyntheticVerifier(n_cycles, drafter.tb.n_nodes, cfg.vocab_size, cfg.hidden_size, dev, seed=7 + rank)
+    # synthetic 32-layer verifier KV cache [layers*2, B, kv_heads, cap, hd]
+    tgt_kv = torch.zeros((64, 1, 32, 2048 + 64, 128), dtype=torch.bfloat16, device=dev)
+
+    with torch.no_grad():
+        rec_lens, _ = run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, True, a.plant, tgt_kv)
+        lens, elapsed = run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, False, a.plant, tgt_kv,
+                                   graph=not a.no_graph, timed_from=a.warmup, timed_n=a.steps, sync=sync)
+    if lens != rec_lens:
+        raise SystemExit(f"timed replay diverged from the recorded generation: {lens} vs {rec_lens}")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    timed_lens = lens[a.warmup:]
+    acc = torch.tensor([sum(timed_lens) + len(timed_lens), len(timed_lens)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(acc)
+    mean_accept = float(acc[0] / acc[1])
+
+    out = {
+        "metric": "draft-tree steps/s (EAGLE-1 draft forward + lm_head + top-k10 per tree depth, incl. greedy verify + compaction per cycle)",
+        "value": world * a.steps * n_fw / elapsed,
+        "unit": "draft-tree steps/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": elapsed / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic (random-init weights, synthetic prompt and verifier outputs)",
+        "config": {"workload": f"BASELINE configs[1]: {a.config} dims EAGLE-1 draft head, static 25-path tree depth 5 / top-k 10 "
+                               f"({a.expand}), greedy verify, batch 1 per GPU, ctx {a.ctx}",
+                   "draft_forwards_per_cycle": n_fw, "hip_graph": not a.no_graph, "replicas": world},
+        "cycles_per_s": world * a.steps / elapsed,
+        "mean_accept_len": mean_accept,
+        "mean_accept_len_note": f"synthetic verifier with planted agreement p={a.plant}; not a model-quality figure",
+    }
+    if rank == 0:
+        with torch.no_grad():
+            out["roofline"] = roofline_lm_head(drafter, rows=4)
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, a.expand)
+    if not a.no_train:
+        try:
+            from eagle_amd.train_bench import train_tokens_per_s
+            tr = train_tokens_per_s(dev, rank, world, dist)
+            if rank == 0 and tr is not None:
+                out["train"] = tr
+        except ImportError:
+            pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

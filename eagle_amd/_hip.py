@@ -39,7 +39,7 @@ SIGNATURES = {
     "eagle_topk_workspace_bytes": (L, [I, I, I]),
     "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P]),
     "eagle_tree_gather_ids": (I, [P, L, P, I, P, I, P]),
-    "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, I, P]),
+    "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, P, P, I, P]),
     "eagle_kv_compact_bf16": (I, [P, L, L, I, I, I, P, I, P, P, I, P, P]),
     "eagle_gather_accepted_bf16": (I, [P, I, I, P, I, P, P, I, P]),
     "eagle_ce_stat_bytes": (I, []),

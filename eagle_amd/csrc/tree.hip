@@ -38,7 +38,8 @@ __global__ __launch_bounds__(64) void greedy_accept_kernel(const int64_t* __rest
                                                           const int64_t* __restrict__ target_argmax,
                                                           const int32_t* __restrict__ prev_len,
                                                           int64_t* __restrict__ tree_tok_out, int64_t* __restrict__ cart_out,
-                                                          int32_t* __restrict__ accept_out, int64_t* __restrict__ result) {
+                                                          int32_t* __restrict__ accept_out, int64_t* __restrict__ result,
+                                                          int64_t* __restrict__ next_ids_out, int32_t* __restrict__ n_acc_out) {
   extern __shared__ int64_t tok[];  // [n_nodes]
   const int b = blockIdx.x, lane = threadIdx.x;
   const int64_t* fl = flat_ids + (int64_t)b * flat_bstride;
@@ -87,18 +88,30 @@ __global__ __launch_bounds__(64) void greedy_accept_kernel(const int64_t* __rest
     result[(int64_t)b * 4 + 1] = best_len;
     result[(int64_t)b * 4 + 2] = tgt[node];
     result[(int64_t)b * 4 + 3] = (prev_len ? prev_len[b] : 0) + best_len + 1;
+    // inputs of the next draft cycle: the token FOLLOWING each accepted hidden row
+    // (accepted draft tokens 1..accept_length, then the verifier's next token), zero padded.
+    if (next_ids_out) {
+      for (int j = 0; j < W; ++j) {
+        int64_t v = 0;
+        if (j < best_len) v = tok[retrieve[(int64_t)best_p * W + j + 1]];
+        else if (j == best_len) v = tgt[node];
+        next_ids_out[(int64_t)b * W + j] = v;
+      }
+    }
+    if (n_acc_out) n_acc_out[b] = best_len + 1;
   }
 }
 
 extern "C" int eagle_greedy_accept(const int64_t* root_token, const int64_t* flat_ids, int64_t flat_batch_stride,
                                    const int64_t* tree_indices, int n_nodes, const int64_t* retrieve, int P, int W,
                                    const int64_t* target_argmax, const int32_t* prev_len, int64_t* tree_tok_out,
-                                   int64_t* cart_out, int32_t* accept_out, int64_t* result, int B, hipStream_t stream) {
+                                   int64_t* cart_out, int32_t* accept_out, int64_t* result, int64_t* next_ids_out,
+                                   int32_t* n_acc_out, int B, hipStream_t stream) {
   if (!root_token || !flat_ids || !tree_indices || !retrieve || !target_argmax || !result) return EAGLE_ERR_ARG;
   if (n_nodes < 1 || n_nodes > 4096 || P < 1 || P >= (1 << 20) || W < 1 || B < 1) return EAGLE_ERR_SHAPE;
   hipLaunchKernelGGL(greedy_accept_kernel, dim3(B), dim3(64), (size_t)n_nodes * 8, stream, root_token, flat_ids,
                      flat_batch_stride, tree_indices, n_nodes, retrieve, P, W, target_argmax, prev_len, tree_tok_out,
-                     cart_out, accept_out, result);
+                     cart_out, accept_out, result, next_ids_out, n_acc_out);
   return eagle_check_launch();
 }
 

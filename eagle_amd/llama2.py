@@ -179,6 +179,42 @@ class Llama2Model(nn.Module):
             c.v[:, :, :pl].copy_(past[1])
         return c
 
+    # ------------------------------------------------------------------ kernel chain
+    def _forward_rows(self, emb_idx, hid, hid_idx, M, B, q_len, pos, past_dev, max_kv, tmask, pad, caches,
+                      past_host=None, past_off0=0):
+        """One draft-head forward over M = B*q_len rows, all in HIP kernels.
+
+        emb_idx [M] int64 rows of embed_tokens; hid [*, D] with optional row gather hid_idx [M];
+        pos [M] int64; past_dev [B] int32 device lengths (+ static offset past_off0 + chunk offset);
+        max_kv: static upper bound on past+q_len when lengths live on the device only
+        (``past_host`` None), else derived from the host length."""
+        dev = hid.device
+        H, HK, hd = self._dims()
+        cos, sin = self._rope_tables(self.config.max_position_embeddings if max_kv is None else max_kv, dev)
+        if self._err is None or self._err.device != dev:
+            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        emb_w = self.embed_tokens.weight
+        if emb_w.dtype != torch.bfloat16:
+            raise TypeError("embed_tokens must be bf16 (cast the model with .to(torch.bfloat16))")
+        # fc(cat(embed_tokens(ids), hidden)) -- eagle/llama2.py:515, :537-542
+        x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M)
+        for li, layer in enumerate(self.layers):
+            a = layer.self_attn
+            cache = caches[li]
+            xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
+            qkv = ops.linear_skinny(xin, self._packed_weights(li))
+            attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
+            for r0 in range(0, q_len, 16):
+                mq = min(16, q_len - r0)
+                bound = (past_host + r0 + mq) if past_host is not None else max_kv
+                ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, past_off0 + r0, tmask, pad, attn, self._err,
+                                   B, mq, H, HK, hd, bound, True, q_len, r0)
+            x = ops.linear_skinny(attn, a.o_proj.weight, res=x)
+            xn = ops.rmsnorm(x, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
+            act = ops.linear_skinny(xn, layer.mlp.gate_proj.weight, W2=layer.mlp.up_proj.weight)
+            x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x)
+        return x
+
     # ------------------------------------------------------------------ forward
     def forward(
         self,
@@ -233,9 +269,7 @@ class Llama2Model(nn.Module):
                 raise IndexError("tree_mask must carry the batch dimension, as the reference's boolean index needs")
             tmask = (tm[:, 0] != 0).to(torch.uint8).contiguous()
             tmask = tmask[0] if B == 1 else tmask
-        cos, sin = self._rope_tables(total, dev)
-        if self._err is None or self._err.device != dev:
-            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._rope_tables(total, dev)
         ids = input_ids.reshape(-1)
         if ids.dtype != torch.int64:
             ids = ids.long()
@@ -243,31 +277,16 @@ class Llama2Model(nn.Module):
         hs = hidden_states.reshape(B * q_len, D)
         if not hs.is_contiguous():
             hs = hs.contiguous()
-        emb_w = self.embed_tokens.weight
-        if emb_w.dtype != torch.bfloat16:
-            raise TypeError("embed_tokens must be bf16 (cast the model with .to(torch.bfloat16))")
         M = B * q_len
-        # fc(cat(embed_tokens(ids), hidden)) -- eagle/llama2.py:515, :537-542
-        x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=ids, x1=hs, M=M)
         past_dev = torch.full((B,), past_len, dtype=torch.int32, device=dev)
-        next_cache = () if use_cache else None
-        for li, layer in enumerate(self.layers):
-            a = layer.self_attn
+        caches = []
+        for li in range(len(self.layers)):
             past = None if past_key_values is None else past_key_values[li]
-            cache = self._cache_for(li, B, total, dev, past)
-            xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
-            qkv = ops.linear_skinny(xin, self._packed_weights(li))
-            attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
-            for r0 in range(0, q_len, 16):
-                mq = min(16, q_len - r0)
-                ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, r0, tmask, pad, attn, self._err,
-                                   B, mq, H, HK, hd, past_len + r0 + mq, True, q_len, r0)
-            x = ops.linear_skinny(attn, a.o_proj.weight, res=x)
-            xn = ops.rmsnorm(x, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
-            act = ops.linear_skinny(xn, layer.mlp.gate_proj.weight, W2=layer.mlp.up_proj.weight)
-            x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x)
-            if use_cache:
-                next_cache += ((cache.k[:, :, :total], cache.v[:, :, :total]),)
+            caches.append(self._cache_for(li, B, total, dev, past))
+        x = self._forward_rows(ids, hs, None, M, B, q_len, pos, past_dev, None, tmask, pad, caches, past_len)
+        next_cache = None
+        if use_cache:
+            next_cache = tuple((c.k[:, :, :total], c.v[:, :, :total]) for c in caches)
         out = x.view(B, q_len, D)
         if use_cache:
             return out, next_cache

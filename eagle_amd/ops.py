@@ -133,31 +133,39 @@ def first_argmax(logits: torch.Tensor) -> torch.Tensor:
     return topk(logits, 1, want_values=False)[1][:, 0]
 
 
-def tree_gather_ids(flat_ids: torch.Tensor, tree_idx: torch.Tensor, B: int = 1, out=None) -> torch.Tensor:
+def tree_gather_ids(flat_ids: torch.Tensor, tree_idx: torch.Tensor, B: int = 1, out=None,
+                    batch_stride: Optional[int] = None) -> torch.Tensor:
+    """out[b][j] = flat_ids[b].flatten()[tree_idx[j]].  ``flat_ids`` may be a view that starts at a
+    request's first row; ``batch_stride`` (elements) then gives the distance between requests."""
     n = tree_idx.numel()
-    flat = flat_ids.reshape(B, -1)
+    if batch_stride is None:
+        flat_ids = flat_ids.reshape(B, -1)
+        batch_stride = flat_ids.stride(0)
     if out is None:
         out = torch.empty((B, n), dtype=torch.int64, device=flat_ids.device)
-    call("eagle_tree_gather_ids", ptr(flat), flat.stride(0), ptr(tree_idx), n, ptr(out), B, stream())
+    call("eagle_tree_gather_ids", ptr(flat_ids), batch_stride, ptr(tree_idx), n, ptr(out), B, stream())
     return out
 
 
 def greedy_accept(root_token: torch.Tensor, flat_ids: torch.Tensor, tree_indices: torch.Tensor,
                   retrieve: torch.Tensor, target_argmax: torch.Tensor, prev_len: Optional[torch.Tensor],
-                  B: int = 1, want_debug: bool = False):
+                  B: int = 1, want_debug: bool = False, next_ids: Optional[torch.Tensor] = None,
+                  n_acc: Optional[torch.Tensor] = None, result: Optional[torch.Tensor] = None):
     """result [B,4] int64 = {best_path, accept_length, next_token, new_len}."""
     n_nodes = tree_indices.numel()
     P_, W = retrieve.shape
     dev = flat_ids.device
     flat = flat_ids.reshape(B, -1)
-    result = torch.empty((B, 4), dtype=torch.int64, device=dev)
+    if result is None:
+        result = torch.empty((B, 4), dtype=torch.int64, device=dev)
     tok = cart = acc = None
     if want_debug:
         tok = torch.empty((B, n_nodes), dtype=torch.int64, device=dev)
         cart = torch.empty((B, P_, W), dtype=torch.int64, device=dev)
         acc = torch.empty((B, P_), dtype=torch.int32, device=dev)
     call("eagle_greedy_accept", ptr(root_token), ptr(flat), flat.stride(0), ptr(tree_indices), n_nodes,
-         ptr(retrieve), P_, W, ptr(target_argmax), ptr(prev_len), ptr(tok), ptr(cart), ptr(acc), ptr(result), B, stream())
+         ptr(retrieve), P_, W, ptr(target_argmax), ptr(prev_len), ptr(tok), ptr(cart), ptr(acc), ptr(result), ptr(next_ids), ptr(n_acc),
+         B, stream())
     return (result, tok, cart, acc) if want_debug else result
 
 

@@ -1,0 +1,158 @@
+"""EAGLE-1 static-tree draft / verify cycle on one MI355X.
+
+``EagleDrafter`` is the device-resident version of upstream EAGLE-1's ``topK_genrate`` +
+``evaluate_posterior`` + ``update_inference_inputs`` that ``Llama2Model.init_tree`` /
+``tree_mask`` (eagle/llama2.py:453-458, :482-488) were written for.  Everything between "the
+verifier produced logits for the tree" and "the next tree is drafted" runs as HIP kernels with
+no host synchronisation: lengths, accepted counts and token ids stay in device memory and all
+shapes are static (the catch-up forward is padded to max_depth+1 rows; the padding rows it
+appends to the KV cache lie beyond the stable length and are overwritten by the tree steps), so a
+whole cycle can be captured into one HIP graph (``capture()``).
+
+Per cycle, for each of B independent requests:
+  catch-up   forward of the accepted tokens on top of the stable KV cache, lm_head on the last
+             valid row, top-k(10)                                           -> flat row 0
+  expansion  per tree depth d: tokens = flat_topk[tree_indices[d]], hidden = parent rows,
+             tree-masked forward at position stable_len + d, lm_head, top-k -> flat rows 1..
+  verify     first-argmax of the verifier's logits per tree node, greedy acceptance along the
+             root->leaf paths, in-place compaction of the verifier's KV cache, gather of the
+             accepted hidden states and of the tokens that follow them.
+The verifier forward itself is out of scope: its logits, hidden states
+and KV cache are inputs.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from . import ops
+from .llama2 import Llama2Model
+from .tree import TreeBuffers, mc_sim_7b_63
+
+BF16 = torch.bfloat16
+
+
+class EagleDrafter:
+    def __init__(self, model: Llama2Model, lm_head_weight: torch.Tensor, tree: Sequence[Sequence[int]] = mc_sim_7b_63,
+                 expand: str = "wchild", batch: int = 1, max_ctx: int = 2048, topk: int = 10):
+        dev = lm_head_weight.device
+        if lm_head_weight.dtype != BF16 or not lm_head_weight.is_cuda:
+            raise TypeError("lm_head weight must be a bf16 device tensor")
+        self.model, self.lm_head, self.B, self.k = model, lm_head_weight.contiguous(), batch, topk
+        self.tb = TreeBuffers(tree, topk=topk, expand=expand, device=dev)
+        self.W = self.tb.max_depth + 1                       # catch-up rows per request (padded)
+        if self.W > 16 or max(len(s.nodes) for s in self.tb.steps) > 16:
+            raise ValueError("the tree attention kernel takes at most 16 query rows per request and step")
+        self.n_fwd = sum(len(s.nodes) for s in self.tb.steps)
+        self.R = 1 + self.n_fwd                              # flat top-k rows per request
+        self.cap = (max_ctx + self.W + self.n_fwd + 255) // 256 * 256
+        self.dev, self.D = dev, model.config.hidden_size
+        B, V = batch, lm_head_weight.shape[0]
+        self.caches = [model._cache_for(li, B, self.cap, dev, None) for li in range(len(model.layers))]
+        self.stable_len = torch.zeros(B, dtype=torch.int32, device=dev)  # final rows of the draft KV cache
+        self.flat_ids = torch.zeros((B, self.R, topk), dtype=torch.int64, device=dev)
+        self.flat_vals = torch.zeros((B, self.R, topk), dtype=BF16, device=dev)
+        self._arW = torch.arange(self.W, dtype=torch.int64, device=dev)
+        self._rowbase = torch.arange(B, dtype=torch.int64, device=dev) * self.W
+        rows_max = B * max(self.W, self.tb.n_nodes, 16)
+        self._ws = torch.empty(ops.query("eagle_topk_workspace_bytes", rows_max, V, topk), dtype=torch.uint8, device=dev)
+        ar_b = torch.arange(B, dtype=torch.int64, device=dev)[:, None]
+        self._hid_idx, prev_n = [], 1
+        for s in self.tb.steps:                               # static batch-major parent-row gathers
+            self._hid_idx.append((ar_b * prev_n + s.parent_row[None, :]).reshape(-1).contiguous())
+            prev_n = len(s.nodes)
+        # verify-side outputs (persistent so a captured graph can be replayed)
+        self.result = torch.zeros((B, 4), dtype=torch.int64, device=dev)
+        self.next_ids = torch.zeros((B, self.W), dtype=torch.int64, device=dev)
+        self.n_acc = torch.ones(B, dtype=torch.int32, device=dev)
+
+    def reset(self):
+        self.stable_len.zero_()
+
+    # -------------------------------------------------------------- draft side
+    def _head_topk(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int, row0: int, n: int):
+        """top-k(lm_head(x[idx])) -> flat rows [row0, row0+n) of every request."""
+        logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
+        if self.B == 1:
+            ops.topk(logits, self.k, out_idx=self.flat_ids[0, row0:row0 + n], out_val=self.flat_vals[0, row0:row0 + n],
+                     workspace=self._ws)
+        else:
+            vals, ids = ops.topk(logits, self.k, workspace=self._ws)
+            self.flat_ids[:, row0:row0 + n] = ids.view(self.B, n, self.k)
+            self.flat_vals[:, row0:row0 + n] = vals.view(self.B, n, self.k)
+
+    def prefill(self, hidden: torch.Tensor, input_ids: torch.Tensor):
+        """First call of a request batch: hidden [B, ctx, D] = verifier hidden states of the prompt,
+        input_ids [B, ctx+1] = prompt tokens plus the verifier's first sampled token.  Equal-length
+        prompts (ragged batches are prefilled request by request into their cache rows)."""
+        B, ctx, D = hidden.shape
+        assert B == self.B and input_ids.shape[1] == ctx + 1
+        m = self.model
+        ids = input_ids[:, 1:].reshape(-1).contiguous()
+        pos = torch.arange(ctx, dtype=torch.int64, device=self.dev).repeat(B)
+        self.stable_len.zero_()
+        x = m._forward_rows(ids, hidden.reshape(B * ctx, D).contiguous(), None, B * ctx, B, ctx, pos, self.stable_len,
+                            None, None, None, self.caches, past_host=0)
+        self.stable_len.fill_(ctx)
+        last = torch.arange(B, dtype=torch.int64, device=self.dev) * ctx + (ctx - 1)
+        self._head_topk(x, last, B, 0, 1)
+        self._expand(x, last)
+        return self.flat_ids, self.flat_vals
+
+    def draft(self, acc_hidden: torch.Tensor, acc_ids: torch.Tensor, n_acc: torch.Tensor):
+        """One expansion.  acc_hidden [B,W,D] bf16 / acc_ids [B,W] int64 hold, per request, the
+        verifier hidden states of the n_acc[b] (device int32, 1..W) newly accepted tokens and the
+        token that FOLLOWS each of them (the draft head pairs hidden[i] with token[i+1]); rows
+        >= n_acc are padding.  Advances the stable length by n_acc.
+        Returns (flat_ids [B,R,k], flat_vals [B,R,k]) -- persistent buffers."""
+        B, W, D, m = self.B, self.W, self.D, self.model
+        pos = (self.stable_len.long()[:, None] + self._arW[None, :]).reshape(-1)
+        x = m._forward_rows(acc_ids.reshape(-1), acc_hidden.reshape(B * W, D), None, B * W, B, W, pos,
+                            self.stable_len, self.cap, None, None, self.caches)
+        last = self._rowbase + (n_acc.long() - 1)             # each request's last valid row
+        self.stable_len += n_acc
+        self._head_topk(x, last, B, 0, 1)
+        self._expand(x, last)
+        return self.flat_ids, self.flat_vals
+
+    def _expand(self, x: torch.Tensor, last: torch.Tensor):
+        B, m = self.B, self.model
+        stride = self.R * self.k
+        off, prev_row0 = 0, 0
+        for d, s in enumerate(self.tb.steps):
+            n = len(s.nodes)
+            ids = ops.tree_gather_ids(self.flat_ids[:, prev_row0], s.tree_indices, B=B, batch_stride=stride)
+            hid_idx = last[:, None].expand(B, n).reshape(-1).contiguous() if d == 0 else self._hid_idx[d]
+            pos = (self.stable_len.long() + d)[:, None].expand(B, n).reshape(-1).contiguous()
+            x = m._forward_rows(ids.reshape(-1), x, hid_idx, B * n, B, n, pos, self.stable_len, self.cap,
+                                s.attn_mask_u8, None, self.caches, past_off0=off)
+            self._head_topk(x, None, B * n, s.row_base, n)
+            off += n
+            prev_row0 = s.row_base
+
+    # -------------------------------------------------------------- verify side
+    def verify(self, root_token: torch.Tensor, target_logits: torch.Tensor, prev_len: torch.Tensor):
+        """target_logits [B, n_nodes, V] (bf16 or fp32): the verifier's logits at every tree node;
+        root_token [B] int64; prev_len [B] int32 = verifier cache rows before the tree.
+        Fills and returns result [B,4] = {best_path, accept_length, next_token, new_len}; also
+        fills next_ids [B,W] and n_acc [B] (inputs of the next ``draft``)."""
+        B, n = self.B, self.tb.n_nodes
+        tgt = ops.topk(target_logits.reshape(B * n, -1), 1, want_values=False, workspace=self._ws)[1].view(B, n)
+        return ops.greedy_accept(root_token, self.flat_ids, self.tb.tree_indices, self.tb.retrieve_indices, tgt,
+                                 prev_len, B=B, next_ids=self.next_ids, n_acc=self.n_acc, result=self.result)
+
+    def compact(self, prev_len: torch.Tensor, target_kv: Optional[torch.Tensor], target_hidden: torch.Tensor,
+                kv_inner: int = 1) -> torch.Tensor:
+        """In-place compaction of the verifier's KV cache ([outer, B, inner, cap, hd], the tree's rows
+        at [prev_len, prev_len+n_nodes)) and gather of the accepted path's hidden states
+        [B, W, D] (zeros beyond accept_length+1) for the next ``draft``."""
+        if target_kv is not None:
+            ops.kv_compact(target_kv, self.B, kv_inner, self.tb.retrieve_indices, self.result, prev_len, self.model._err)
+        return ops.gather_accepted(target_hidden, self.tb.retrieve_indices, self.result, B=self.B)
+
+    def check_errors(self):
+        """Host-side look at the device error flag (sync point; not for the hot loop)."""
+        e = int(self.model._err.item()) if self.model._err is not None else 0
+        if e:
+            raise ops._hip.HipKernelError(f"device-side bound violation (flag {e}): KV cache capacity exceeded")

@@ -91,12 +91,14 @@ int eagle_tree_gather_ids(const int64_t* flat_ids, int64_t flat_batch_stride, co
                           int n, int64_t* out_ids, int B, eagle_stream_t stream);
 /* Greedy acceptance along the tree's root->leaf paths.  result[b] = {best_path, accept_length,
  * next_token, prev_len[b] + accept_length + 1}; optional tree_tok_out [B,n_nodes],
- * cart_out [B,P,W], accept_out [B,P]. */
+ * cart_out [B,P,W], accept_out [B,P]; optional next_ids_out [B,W] = the token following each
+ * accepted hidden row (accepted draft tokens, then next_token; zero padded) and n_acc_out [B] =
+ * accept_length + 1: the inputs of the next draft cycle. */
 int eagle_greedy_accept(const int64_t* root_token, const int64_t* flat_ids, int64_t flat_batch_stride,
                         const int64_t* tree_indices, int n_nodes, const int64_t* retrieve, int P, int W,
                         const int64_t* target_argmax, const int32_t* prev_len, int64_t* tree_tok_out,
-                        int64_t* cart_out, int32_t* accept_out, int64_t* result, int B,
-                        eagle_stream_t stream);
+                        int64_t* cart_out, int32_t* accept_out, int64_t* result, int64_t* next_ids_out,
+                        int32_t* n_acc_out, int B, eagle_stream_t stream);
 /* In-place compaction of the accepted path's KV rows: cache viewed as [n_slabs][cap][row_elems]
  * with slab = (outer*B + b)*inner + i; rows prev_len[b] + retrieve[best][j] -> prev_len[b] + j. */
 int eagle_kv_compact_bf16(void* cache, int64_t n_slabs, int64_t slab_stride, int row_elems, int B,

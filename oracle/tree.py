@@ -177,7 +177,7 @@ DraftFn = Callable[..., Tuple[torch.Tensor, tuple]]
 
 
 def topk_generate(draft_fn: DraftFn, lm_head_w: torch.Tensor, tb: TreeBuffers,
-                  hidden_states: torch.Tensor, input_ids: torch.Tensor, stable_kv=None):
+                  hidden_states: torch.Tensor, input_ids: torch.Tensor, stable_kv=None, head_fn=None):
     """The expansion loop (upstream cnets.py ``topK_genrate``, greedy branch).
 
     hidden_states [1, n_new, D]: target hidden states of the tokens not yet in ``stable_kv``.
@@ -185,15 +185,20 @@ def topk_generate(draft_fn: DraftFn, lm_head_w: torch.Tensor, tb: TreeBuffers,
       first token is dropped (the draft head pairs hidden[i] with token[i+1]).
     draft_fn(hidden, ids, past_key_values=, position_ids=, tree_mask=, use_cache=True)
       -> (out_hidden, kv).
+    head_fn(hidden [rows, D]) -> logits [rows, V]; default: the frozen lm_head as a bias-free
+      Linear (eagle/train.py:215-228).
     Returns (flat_topk_ids [1+n_fwd, k], flat_topk_vals, new_stable_kv, debug dict).
     """
+    if head_fn is None:
+        def head_fn(h):
+            return torch.nn.functional.linear(h, lm_head_w)
     ids = input_ids[:, 1:]
     len_posi = ids.shape[1]
     kv_len = 0 if stable_kv is None else stable_kv[0][0].shape[2]
     out_hidden, kv = draft_fn(hidden_states, ids[:, kv_len:], past_key_values=stable_kv,
                               position_ids=None, tree_mask=None, use_cache=True)
     new_stable = kv
-    logits = torch.nn.functional.linear(out_hidden[:, -1], lm_head_w)  # [1,V]
+    logits = head_fn(out_hidden[:, -1])  # [1,V]
     all_ids, all_vals, step_inputs = [], [], []
     for d in range(len(tb.step_nodes)):
         vals, idx = stable_topk(logits, tb.topk)
@@ -207,7 +212,7 @@ def topk_generate(draft_fn: DraftFn, lm_head_w: torch.Tensor, tb: TreeBuffers,
         out_hidden, kv = draft_fn(hid, sel[None, :], past_key_values=kv, position_ids=pos,
                                   tree_mask=tb.step_attn_mask[d], use_cache=True)
         len_posi += 1
-        logits = torch.nn.functional.linear(out_hidden[0], lm_head_w)
+        logits = head_fn(out_hidden[0])
     vals, idx = stable_topk(logits, tb.topk)
     all_ids.append(idx)
     all_vals.append(vals)

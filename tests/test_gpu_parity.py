@@ -339,3 +339,88 @@ def test_sharded_ce_partials_combine_exactly_like_unsharded():
     assert torch.equal(r2[:, 2], r1[:, 2])
     ex = ol.exact_loss_from_logits(t, o, torch.zeros(N, 8), torch.zeros(N, 8), torch.ones(N))
     assert int(s2[2]) == int(ex["correct"])
+
+
+# ------------------------------------------------------------------ draft / verify cycle
+@pytest.mark.parametrize("expand", ["wchild", "all"])
+def test_drafter_cycle_matches_oracle_loop(expand):
+    """The device-resident cycle (padded catch-up, device lengths, device top-k / gathers) against
+    the oracle's expansion loop + acceptance + compaction.  Both sides get their logits from the
+    same HIP kernels (the oracle loop calls the public Llama2Model.forward and the lm_head GEMM), so
+    top-k ids, tree tokens, acceptance lengths and compaction must agree bit for bit; the kernels'
+    numerics are checked against the CPU oracle elsewhere in this file."""
+    from eagle_amd import ops
+    from eagle_amd.speculative import EagleDrafter
+    d = dev()
+    dims = dm.DraftDims(hidden=256, inter=512, heads=2, kv_heads=2, vocab=2000)
+    w = dm.init_weights(dims, seed=21, std=0.08)
+    g = torch.Generator().manual_seed(33)
+    lm_head = (torch.randn(dims.vocab, dims.hidden, generator=g) * 0.3).to(BF).to(d)
+    m_api = _model(dims, w)      # driven through the public forward by the oracle loop
+    m_dev = _model(dims, w)      # driven by the drafter
+    tb_o = ot.generate_tree_buffers(expand=expand)
+    drafter = EagleDrafter(m_dev, lm_head, expand=expand, batch=1, max_ctx=256)
+    W, n_nodes = drafter.W, tb_o.n_nodes
+
+    def draft_fn(h, ids, past_key_values=None, position_ids=None, tree_mask=None, use_cache=True):
+        m_api.tree_mask = None if tree_mask is None else tree_mask.to(d)
+        pk = None if past_key_values is None else tuple((k.to(d), v.to(d)) for k, v in past_key_values)
+        with torch.no_grad():
+            o, kv = m_api(h.to(d), ids.to(d), past_key_values=pk,
+                          position_ids=None if position_ids is None else position_ids.to(d), use_cache=True)
+        return o.cpu(), tuple((k.cpu().clone(), v.cpu().clone()) for k, v in kv)
+
+    def head_fn(h):
+        return ops.linear_skinny(h.to(d).contiguous(), lm_head).cpu()
+
+    ctx = 23
+    tokens = torch.randint(0, dims.vocab, (1, ctx + 1), generator=g)
+    hidden = torch.randn(1, ctx, dims.hidden, generator=g).to(BF)
+    ids_o, vals_o, stable, _ = ot.topk_generate(draft_fn, None, tb_o, hidden, tokens, None, head_fn=head_fn)
+    ids_g, vals_g = drafter.prefill(hidden.to(d), tokens.to(d))
+    assert torch.equal(ids_g[0].cpu(), ids_o), "prefill cycle: flat top-k ids differ"
+    assert torch.equal(vals_g[0].cpu(), vals_o)
+
+    prev_len = ctx
+    tgt_kv = torch.randn(2, 1, 2, 128, 16, generator=g).to(BF)     # synthetic verifier cache [outer,B,inner,cap,hd]
+    tgt_kv_g = tgt_kv.to(d).clone()
+    accepted_lengths = []
+    for cycle in range(4):
+        # synthetic verifier outputs for the 26 tree nodes; plant agreement down a path
+        tgt_logits = (torch.randn(n_nodes, dims.vocab, generator=g) * 2).to(BF)
+        tgt_hidden = torch.randn(1, n_nodes, dims.hidden, generator=g).to(BF)
+        root = int(tokens[0, -1])
+        tree_tok, cart = ot.tree_candidates(root, ids_o, tb_o)
+        node = 0
+        for _ in range(cycle + 1):
+            kids = [i for i in range(n_nodes) if tb_o.parent[i] == node]
+            if not kids:
+                break
+            tgt_logits[node, int(tree_tok[kids[0]])] = 50.0
+            node = kids[0]
+        tgt_arg = ot.first_argmax(tgt_logits)
+        best, alen, nxt, acc = ot.greedy_accept(cart, tgt_arg, tb_o)
+        ref_kv = tgt_kv.clone()
+        new_len, acc_h = ot.compact([ref_kv], tgt_hidden, tb_o, best, alen, prev_len)
+        # --- device side
+        prev_dev = torch.tensor([prev_len], dtype=torch.int32, device=d)
+        res = drafter.verify(tokens[:, -1].to(d), tgt_logits.to(d)[None], prev_dev)
+        acc_h_g = drafter.compact(prev_dev, tgt_kv_g, tgt_hidden.to(d))
+        assert res[0].tolist() == [best, alen, nxt, new_len]
+        assert int(drafter.n_acc[0]) == alen + 1
+        path_tokens = [int(cart[best, j]) for j in range(1, alen + 1)] + [nxt]
+        assert drafter.next_ids[0, : alen + 1].tolist() == path_tokens
+        assert torch.equal(tgt_kv_g.cpu(), ref_kv)
+        assert torch.equal(acc_h_g[0, : alen + 1].cpu(), acc_h[0])
+        accepted_lengths.append(alen)
+        tgt_kv = ref_kv
+        # --- next expansion on both sides
+        tokens = torch.cat([tokens, torch.tensor([path_tokens])], dim=1)
+        ids_o, vals_o, stable, _ = ot.topk_generate(draft_fn, None, tb_o, acc_h, tokens, stable, head_fn=head_fn)
+        ids_g, vals_g = drafter.draft(acc_h_g, drafter.next_ids, drafter.n_acc)
+        assert torch.equal(ids_g[0].cpu(), ids_o), f"cycle {cycle}: flat top-k ids differ"
+        assert torch.equal(vals_g[0].cpu(), vals_o)
+        prev_len = new_len
+        assert int(drafter.stable_len[0]) == stable[0][0].shape[2] == tokens.shape[1] - 1
+    assert max(accepted_lengths) >= 2
+    drafter.check_errors()
