@@ -110,12 +110,11 @@ def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, pla
         tl = ver.logits.index_select(0, cyc)           # [1, n_nodes, V]  (B == 1 per replica)
         th = ver.hidden.index_select(0, cyc)
         res = drafter.verify(root, tl, prev_len)
-        acc_h = drafter.compact(prev_len, tgt_kv, th, kv_inner=tgt_kv.shape[2] if tgt_kv is not None else 1)
-        res_log.index_copy_(0, cyc, res[None])
-        root.copy_(res[:, 2])
-        prev_len.copy_(res[:, 3])
+        acc_h = drafter.compact(prev_len, tgt_kv, th, kv_inner=tgt_kv.shape[2] if tgt_kv is not None else 1,
+                                root_io=root, update_prev_len=True)
+        res_log.index_copy_(0, cyc, res[None])   # harness bookkeeping (acceptance log, verifier pool cursor)
         cyc.add_(1)
-        drafter.draft(acc_h, drafter.next_ids, drafter.n_acc)
+        drafter.draft(acc_h, drafter.next_ids)
 
     g = None
     elapsed = 0.0
@@ -234,6 +233,8 @@ def main():
     cfg, model, lm_head = make_model(a.config, dev, seed=0)
     drafter = EagleDrafter(model, lm_head, expand=a.expand, batch=1, max_ctx=2048)
     n_fw = 1 + len(drafter.tb.steps)
+    # the host knows an upper bound of the context for the whole run: tighter attention grids
+    drafter.kv_bound = min(drafter.cap, (a.ctx + (a.warmup + a.steps + 1) * drafter.W + drafter.n_fwd + 63) // 64 * 64)
     n_cycles = a.warmup + a.steps
     if a.ctx + n_cycles * drafter.W > 2048:
         raise SystemExit("ctx + cycles*W exceeds the 2048-token cache of this bench")

@@ -29,19 +29,19 @@ class HipKernelError(RuntimeError):
 # name -> (restype, argtypes).  Mirrors include/eagle_hip.h one to one.
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
-    "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
+    "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, I, L, F, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
     "eagle_rmsnorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),
     "eagle_rmsnorm_bwd_workspace_bytes": (L, [I, I]),
     "eagle_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, P, I, P, I, I, P]),
-    "eagle_attn_decode_lds_bytes": (L, [I]),
-    "eagle_tree_attention_bf16": (I, [P, L, P, P, P, I, P, P, L, I, P, I, P, I, L, P, L, P, L, P,
+    "eagle_attn_decode_workspace_bytes": (L, [I, I, I]),
+    "eagle_tree_attention_bf16": (I, [P, L, P, I, I, P, P, I, P, P, L, I, P, I, P, I, L, P, L, P, L, P, P,
                                       I, I, I, I, I, I, I, I, I, P]),
     "eagle_topk_workspace_bytes": (L, [I, I, I]),
     "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P]),
     "eagle_tree_gather_ids": (I, [P, L, P, I, P, I, P]),
-    "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, P, P, I, P]),
+    "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, P, P, P, P, I, P, P, I, P]),
     "eagle_kv_compact_bf16": (I, [P, L, L, I, I, I, P, I, P, P, I, P, P]),
-    "eagle_gather_accepted_bf16": (I, [P, I, I, P, I, P, P, I, P]),
+    "eagle_gather_accepted_bf16": (I, [P, I, I, P, I, P, P, P, P, I, P]),
     "eagle_ce_stat_bytes": (I, []),
     "eagle_ce_partial_bf16": (I, [P, P, L, I, I, I, P, P, I, P, P]),
     "eagle_ce_combine": (I, [P, I, I, P, P, P, P, P, P]),

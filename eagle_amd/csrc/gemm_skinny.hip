@@ -22,6 +22,8 @@
 
 struct SkinnyArgs {
   const bf16_t* x0; const int64_t* idx0; int64_t ld0; int K0;
+  const int64_t* ind0; int ind_n; int64_t idx0_bstride;  // idx0 row = idx0[(m/ind_n)*bstride + ind0[m%ind_n]]
+  float norm_eps;                                        // > 0: scale row m by rsqrt(mean(x[m]^2) + eps)
   const bf16_t* x1; const int64_t* idx1; int64_t ld1;
   const bf16_t* W; const bf16_t* W2;
   const bf16_t* bias; const bf16_t* res; int64_t ldr;
@@ -33,6 +35,7 @@ template <int RT, int MT, int EPI>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
   constexpr int NT = RT * MT;
   __shared__ __attribute__((aligned(16))) float red[SK_WAVES][NT][64][4];
+  __shared__ float red_ss[SK_WAVES][MT][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int rows_per_block = (EPI == EPI_SILU_MUL) ? 16 : RT * 16;
@@ -55,7 +58,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
     mvalid[mt] = m < p.M;
     int64_t ra = 0, rb = 0;
     if (mvalid[mt]) {
-      ra = p.idx0 ? p.idx0[m] : m;
+      if (p.ind0) ra = p.idx0[(int64_t)(m / p.ind_n) * p.idx0_bstride + p.ind0[m % p.ind_n]];
+      else ra = p.idx0 ? p.idx0[m] : m;
       rb = p.idx1 ? p.idx1[m] : m;
     }
     xa[mt] = p.x0 + ra * p.ld0 + 8 * g;
@@ -63,10 +67,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
   }
 
   f32x4 acc[RT][MT];
+  float ssq[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) ssq[mt] = 0.f;
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_norm = p.norm_eps > 0.f;
 
   const int nfull = p.K >> 7;
   for (int ss = wave; ss < nfull; ss += SK_WAVES) {
@@ -91,6 +99,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
           acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][t], b[s][mt], acc[t][mt], 0, 0, 0);
+    if (do_norm) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float xv = (float)b[s][mt][j]; ssq[mt] = fmaf(xv, xv, ssq[mt]); }
+    }
   }
   // tail: K % 128 in {32, 64, 96}, taken by the wave whose turn it would be
   const int tail_steps = (p.K & 127) >> 5;
@@ -111,6 +127,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
           acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b[mt], acc[t][mt], 0, 0, 0);
+      if (do_norm) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float xv = (float)b[mt][j]; ssq[mt] = fmaf(xv, xv, ssq[mt]); }
+      }
     }
   }
 
@@ -120,8 +142,28 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
       *reinterpret_cast<f32x4*>(&red[wave][t * MT + mt][lane][0]) = acc[t][mt];
+  if (do_norm) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float v = ssq[mt];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) red_ss[wave][mt][r16] = v;
+    }
+  }
   __syncthreads();
   if (wave != 0) return;
+  float rstd[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    rstd[mt] = 1.f;
+    if (do_norm) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) v += red_ss[w][mt][r16];
+      rstd[mt] = rsqrtf(v / (float)p.K + p.norm_eps);
+    }
+  }
 #pragma unroll
   for (int t = 0; t < RT; ++t)
 #pragma unroll
@@ -129,7 +171,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
       f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int w = 0; w < SK_WAVES; ++w) s += *reinterpret_cast<const f32x4*>(&red[w][t * MT + mt][lane][0]);
-      acc[t][mt] = s;
+      acc[t][mt] = s * rstd[mt];
     }
 
   // epilogue: D layout of mfma 16x16: col = lane&15 (token), row = 4*(lane>>4)+r (feature)
@@ -191,12 +233,15 @@ static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) 
 
 // See include/eagle_hip.h for the contract.
 extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int K0,
+                                      const int64_t* ind0, int ind_n, int64_t idx0_bstride, float norm_eps,
                                       const void* x1, const int64_t* idx1, int64_t ld1,
                                       const void* W, const void* W2, const void* bias,
                                       const void* res, int64_t ldr, void* out, int64_t ldo,
                                       int M, int N, int K, int epi, hipStream_t stream) {
   if (!x0 || !W || !out) return EAGLE_ERR_ARG;
   if (epi != EPI_LINEAR && epi != EPI_SILU_MUL) return EAGLE_ERR_ARG;
+  if (ind0 && (!idx0 || ind_n < 1 || M > (epi == EPI_SILU_MUL ? 32 : 64))) return EAGLE_ERR_ARG;
+  if (norm_eps < 0.f || (norm_eps > 0.f && x1)) return EAGLE_ERR_ARG;
   if (epi == EPI_SILU_MUL && (!W2 || bias || res)) return EAGLE_ERR_ARG;
   if (M < 1 || N < 1 || K < 32 || (K & 31)) return EAGLE_ERR_SHAPE;
   if (x1) { if (K0 <= 0 || K0 >= K || (K0 & 31) || (ld1 & 7) || !al16(x1)) return EAGLE_ERR_SHAPE; }
@@ -211,6 +256,7 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     const int mc = (M - m0) < chunk ? (M - m0) : chunk;
     a.x0 = (const bf16_t*)x0 + (idx0 ? 0 : (int64_t)m0 * ld0); a.idx0 = idx0 ? idx0 + m0 : nullptr;
     a.ld0 = ld0; a.K0 = K0;
+    a.ind0 = ind0; a.ind_n = ind_n; a.idx0_bstride = idx0_bstride; a.norm_eps = norm_eps;
     a.x1 = x1 ? (const bf16_t*)x1 + (idx1 ? 0 : (int64_t)m0 * ld1) : nullptr; a.idx1 = idx1 ? idx1 + m0 : nullptr;
     a.ld1 = ld1;
     a.W = (const bf16_t*)W; a.W2 = (const bf16_t*)W2; a.bias = (const bf16_t*)bias;

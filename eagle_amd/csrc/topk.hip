@@ -6,25 +6,25 @@
 // Order: value descending, then index ascending (== a stable descending sort); -0.0 == +0.0;
 // NaN sorts above +inf (torch.sort semantics).  Results are bit-exact against the oracle.
 //
-// Two stages, both wavefront-level selects over 64-bit keys
-//     key = (monotone(value) << 32) | (0xFFFFFFFF - index)
-// so that one unsigned max gives "largest value, lowest index":
-//   stage 1: grid (chunks of 4096 logits) x rows; each lane holds 16 keys in registers, k
-//            rounds of {wave max via DPP shuffles -> block max via LDS -> owner removes};
-//   stage 2: one wave per row merges chunks x k candidates the same way.
+// Wavefront-level select: every element becomes an unsigned key whose max is "largest value,
+// lowest index"; a wave finds its maximum with a 6-step DPP reduction (quad_perm, row mirrors,
+// row_bcast15/31 -- no LDS, no ds_bpermute), the owning lane retires it, k rounds.
+//   stage 1: one wave per 1024 logits (16 per lane, 32 contiguous bytes): k candidates per wave.
+//            bf16 logits use a single 32-bit key (16-bit monotone value | 10-bit local index).
+//   stage 2: one workgroup per row: each wave reduces its share of the candidates to k, wave 0
+//            merges the 4 x k survivors and writes ids (int64) and values.
 #include "common.h"
 
 #define TK_THREADS 256
-#define TK_CHUNK 4096
-#define TK_PER_THREAD (TK_CHUNK / TK_THREADS)  // 16
+#define TK_WCHUNK 1024                 // logits per wave in stage 1
+#define TK_PER_LANE (TK_WCHUNK / 64)   // 16
 #define TK_MAXK 16
-#define TK_CMAX 16  // stage-2 candidates per lane -> chunks*k <= 1024
+#define TK_CM 8                        // stage-2 candidates per thread -> wavechunks*k <= 2048
 
-__device__ __forceinline__ uint32_t mono_bf16(bf16_t b) {
-  if ((b & 0x7fff) > 0x7f80) return 0xffff0000u;   // NaN: largest
+__device__ __forceinline__ uint32_t mono_bf16(bf16_t b) {  // 16-bit monotone key in the low half
+  if ((b & 0x7fff) > 0x7f80) return 0xffffu;       // NaN: largest
   if (b == 0x8000) b = 0;                          // -0.0 == +0.0
-  uint16_t m = (b & 0x8000) ? (uint16_t)~b : (uint16_t)(b | 0x8000);
-  return ((uint32_t)m) << 16;
+  return (b & 0x8000) ? (uint32_t)(uint16_t)~b : (uint32_t)(b | 0x8000);
 }
 __device__ __forceinline__ uint32_t mono_f32(float f) {
   uint32_t u = __float_as_uint(f);
@@ -33,85 +33,71 @@ __device__ __forceinline__ uint32_t mono_f32(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    unsigned long long x = __shfl_xor(v, o, 64);
-    v = x > v ? x : v;
-  }
-  return v;
+// full-wave unsigned max, result uniform (read from lane 63)
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+  uint32_t t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, false); v = v > t ? v : t;   // quad_perm [1,0,3,2]
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, false); v = v > t ? v : t;   // quad_perm [2,3,0,1]
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xf, 0xf, false); v = v > t ? v : t;  // row_half_mirror
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xf, 0xf, false); v = v > t ? v : t;  // row_mirror
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;  // row_bcast15 -> rows 1,3
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;  // row_bcast31 -> rows 2,3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) {
+  const uint32_t hi = wave_umax((uint32_t)(v >> 32));
+  const uint32_t lo = wave_umax(((uint32_t)(v >> 32) == hi) ? (uint32_t)v : 0u);
+  return ((unsigned long long)hi << 32) | lo;
 }
 
-template <typename T>
-__global__ __launch_bounds__(TK_THREADS) void topk_stage1_kernel(const T* __restrict__ x, int64_t ld, int V, int k,
-                                                                unsigned long long* __restrict__ cand) {
-  __shared__ unsigned long long sh[4];
-  const int row = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const T* xr = x + (int64_t)row * ld;
-  unsigned long long key[TK_PER_THREAD];
-  const int base = chunk * TK_CHUNK + t * TK_PER_THREAD;
+// ---- stage 1, bf16: 32-bit keys ----
+__global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, int k,
+                                                                     int nwc, unsigned long long* __restrict__ cand) {
+  const int row = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wc >= nwc) return;
+  const bf16_t* xr = x + (int64_t)row * ld;
+  const int base = wc * TK_WCHUNK + lane * TK_PER_LANE;
+  uint32_t key[TK_PER_LANE];
+  const bool vec = ((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (base + TK_PER_LANE <= V);
+  if (vec) {
+    const uint4 a = *reinterpret_cast<const uint4*>(xr + base);
+    const uint4 b = *reinterpret_cast<const uint4*>(xr + base + 8);
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-  for (int i = 0; i < TK_PER_THREAD; ++i) {
-    const int idx = base + i;
-    unsigned long long kk = 0;
-    if (idx < V) {
-      uint32_t m;
-      if (sizeof(T) == 2) m = mono_bf16(((const bf16_t*)xr)[idx]); else m = mono_f32(((const float*)xr)[idx]);
-      kk = ((unsigned long long)m << 32) | (unsigned long long)(0xffffffffu - (uint32_t)idx);
+    for (int i = 0; i < 8; ++i) {
+      key[2 * i] = (mono_bf16((bf16_t)(w[i] & 0xffff)) << 16) | (uint32_t)(TK_WCHUNK - 1 - (lane * TK_PER_LANE + 2 * i));
+      key[2 * i + 1] = (mono_bf16((bf16_t)(w[i] >> 16)) << 16) | (uint32_t)(TK_WCHUNK - 1 - (lane * TK_PER_LANE + 2 * i + 1));
     }
-    key[i] = kk;
-  }
-  unsigned long long best = 0;
+  } else {
 #pragma unroll
-  for (int i = 0; i < TK_PER_THREAD; ++i) best = key[i] > best ? key[i] : best;
-  for (int r = 0; r < k; ++r) {
-    unsigned long long wm = wave_max_u64(best);
-    if (lane == 0) sh[wave] = wm;
-    __syncthreads();
-    unsigned long long bm = sh[0];
-    bm = sh[1] > bm ? sh[1] : bm;
-    bm = sh[2] > bm ? sh[2] : bm;
-    bm = sh[3] > bm ? sh[3] : bm;
-    __syncthreads();
-    if (t == 0) cand[((int64_t)row * nchunks + chunk) * k + r] = bm;
-    if (bm != 0 && best == bm) {  // keys are unique: exactly one owner
-      best = 0;
-#pragma unroll
-      for (int i = 0; i < TK_PER_THREAD; ++i) {
-        if (key[i] == bm) key[i] = 0;
-        best = key[i] > best ? key[i] : best;
-      }
+    for (int i = 0; i < TK_PER_LANE; ++i) {
+      const int idx = base + i;
+      // invalid slots get key 0
+      key[i] = idx < V ? ((mono_bf16(xr[idx]) << 16) | (uint32_t)(TK_WCHUNK - 1 - (lane * TK_PER_LANE + i))) : 0u;
     }
   }
-}
-
-template <typename T>
-__global__ __launch_bounds__(64) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
-                                                        const T* __restrict__ x, int64_t ld,
-                                                        int64_t* __restrict__ out_idx, T* __restrict__ out_val) {
-  const int row = blockIdx.x, lane = threadIdx.x;
-  unsigned long long key[TK_CMAX];
+  // valid keys are > 0: the smallest value part is 0x007f (-inf); NaN patterns map to 0xffff
+  uint32_t best = 0;
 #pragma unroll
-  for (int i = 0; i < TK_CMAX; ++i) {
-    const int c = lane + i * 64;
-    key[i] = c < ncand ? cand[(int64_t)row * ncand + c] : 0ull;
-  }
-  unsigned long long best = 0;
-#pragma unroll
-  for (int i = 0; i < TK_CMAX; ++i) best = key[i] > best ? key[i] : best;
+  for (int i = 0; i < TK_PER_LANE; ++i) best = key[i] > best ? key[i] : best;
+  unsigned long long* out = cand + ((int64_t)row * nwc + wc) * k;
   for (int r = 0; r < k; ++r) {
-    const unsigned long long bm = wave_max_u64(best);
+    const uint32_t bm = wave_umax(best);
     if (lane == 0) {
-      // fewer than k finite entries can only happen when V < k; emit index -1 then
-      const int64_t idx = bm ? (int64_t)(0xffffffffu - (uint32_t)(bm & 0xffffffffu)) : -1;
-      out_idx[(int64_t)row * k + r] = idx;
-      if (out_val) out_val[(int64_t)row * k + r] = idx >= 0 ? x[(int64_t)row * ld + idx] : (T)0;
+      unsigned long long o = 0;
+      if (bm) {
+        const uint32_t local = TK_WCHUNK - 1 - (bm & 0xffffu);
+        const uint32_t gidx = (uint32_t)(wc * TK_WCHUNK) + local;
+        o = ((unsigned long long)(bm & 0xffff0000u) << 32) | (unsigned long long)(0xffffffffu - gidx);
+      }
+      out[r] = o;
     }
     if (bm != 0 && best == bm) {
       best = 0;
 #pragma unroll
-      for (int i = 0; i < TK_CMAX; ++i) {
+      for (int i = 0; i < TK_PER_LANE; ++i) {
         if (key[i] == bm) key[i] = 0;
         best = key[i] > best ? key[i] : best;
       }
@@ -119,9 +105,85 @@ __global__ __launch_bounds__(64) void topk_stage2_kernel(const unsigned long lon
   }
 }
 
+// ---- stage 1, fp32: 64-bit keys ----
+__global__ __launch_bounds__(TK_THREADS) void topk_stage1_f32_kernel(const float* __restrict__ x, int64_t ld, int V, int k,
+                                                                    int nwc, unsigned long long* __restrict__ cand) {
+  const int row = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int wc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wc >= nwc) return;
+  const float* xr = x + (int64_t)row * ld;
+  const int base = wc * TK_WCHUNK + lane * TK_PER_LANE;
+  unsigned long long key[TK_PER_LANE];
+#pragma unroll
+  for (int i = 0; i < TK_PER_LANE; ++i) {
+    const int idx = base + i;
+    key[i] = idx < V ? (((unsigned long long)mono_f32(xr[idx]) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)idx)) : 0ull;
+  }
+  unsigned long long best = 0;
+#pragma unroll
+  for (int i = 0; i < TK_PER_LANE; ++i) best = key[i] > best ? key[i] : best;
+  unsigned long long* out = cand + ((int64_t)row * nwc + wc) * k;
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long bm = wave_umax64(best);
+    if (lane == 0) out[r] = bm;
+    if (bm != 0 && best == bm) {
+      best = 0;
+#pragma unroll
+      for (int i = 0; i < TK_PER_LANE; ++i) {
+        if (key[i] == bm) key[i] = 0;
+        best = key[i] > best ? key[i] : best;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
+                                                                const T* __restrict__ x, int64_t ld,
+                                                                int64_t* __restrict__ out_idx, T* __restrict__ out_val) {
+  __shared__ unsigned long long surv[4 * TK_MAXK];
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned long long key[TK_CM];
+#pragma unroll
+  for (int i = 0; i < TK_CM; ++i) {
+    const int c = t + i * TK_THREADS;
+    key[i] = c < ncand ? cand[(int64_t)row * ncand + c] : 0ull;
+  }
+  unsigned long long best = 0;
+#pragma unroll
+  for (int i = 0; i < TK_CM; ++i) best = key[i] > best ? key[i] : best;
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long bm = wave_umax64(best);
+    if (lane == 0) surv[wave * TK_MAXK + r] = bm;
+    if (bm != 0 && best == bm) {
+      best = 0;
+#pragma unroll
+      for (int i = 0; i < TK_CM; ++i) {
+        if (key[i] == bm) key[i] = 0;
+        best = key[i] > best ? key[i] : best;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  unsigned long long mine = 0;
+  if (lane < 4 * k) mine = surv[(lane / k) * TK_MAXK + (lane % k)];
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long bm = wave_umax64(mine);
+    if (lane == 0) {
+      // fewer than k entries can only happen when V < k; emit index -1 then
+      const int64_t idx = bm ? (int64_t)(0xffffffffu - (uint32_t)(bm & 0xffffffffu)) : -1;
+      out_idx[(int64_t)row * k + r] = idx;
+      if (out_val) out_val[(int64_t)row * k + r] = idx >= 0 ? x[(int64_t)row * ld + idx] : (T)0;
+    }
+    if (bm != 0 && mine == bm) mine = 0;
+  }
+}
+
 extern "C" int64_t eagle_topk_workspace_bytes(int rows, int V, int k) {
-  const int64_t nchunks = (V + TK_CHUNK - 1) / TK_CHUNK;
-  return (int64_t)rows * nchunks * k * 8;
+  const int64_t nwc = (V + TK_WCHUNK - 1) / TK_WCHUNK;
+  return (int64_t)rows * nwc * k * 8;
 }
 
 // dtype: 0 = bf16 logits, 1 = fp32 logits
@@ -129,17 +191,17 @@ extern "C" int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int r
                                 int64_t* out_idx, void* out_val, void* workspace, hipStream_t stream) {
   if (!logits || !out_idx || !workspace) return EAGLE_ERR_ARG;
   if (rows < 1 || V < 1 || k < 1 || k > TK_MAXK || ld < V) return EAGLE_ERR_SHAPE;
-  const int nchunks = (V + TK_CHUNK - 1) / TK_CHUNK;
-  if (nchunks * k > 64 * TK_CMAX) return EAGLE_ERR_SHAPE;
+  const int nwc = (V + TK_WCHUNK - 1) / TK_WCHUNK;
+  if ((int64_t)nwc * k > TK_THREADS * TK_CM) return EAGLE_ERR_SHAPE;
   unsigned long long* cand = (unsigned long long*)workspace;
-  dim3 g1(nchunks, rows);
+  dim3 g1((nwc + 3) / 4, rows);
   if (dtype == 0) {
-    hipLaunchKernelGGL(topk_stage1_kernel<bf16_t>, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, cand);
-    hipLaunchKernelGGL(topk_stage2_kernel<bf16_t>, dim3(rows), dim3(64), 0, stream, cand, nchunks * k, k,
+    hipLaunchKernelGGL(topk_stage1_bf16_kernel, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand);
+    hipLaunchKernelGGL(topk_stage2_kernel<bf16_t>, dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                        (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val);
   } else if (dtype == 1) {
-    hipLaunchKernelGGL(topk_stage1_kernel<float>, g1, dim3(TK_THREADS), 0, stream, (const float*)logits, ld, V, k, cand);
-    hipLaunchKernelGGL(topk_stage2_kernel<float>, dim3(rows), dim3(64), 0, stream, cand, nchunks * k, k,
+    hipLaunchKernelGGL(topk_stage1_f32_kernel, g1, dim3(TK_THREADS), 0, stream, (const float*)logits, ld, V, k, nwc, cand);
+    hipLaunchKernelGGL(topk_stage2_kernel<float>, dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                        (const float*)logits, ld, out_idx, (float*)out_val);
   } else {
     return EAGLE_ERR_ARG;

@@ -39,7 +39,9 @@ __global__ __launch_bounds__(64) void greedy_accept_kernel(const int64_t* __rest
                                                           const int32_t* __restrict__ prev_len,
                                                           int64_t* __restrict__ tree_tok_out, int64_t* __restrict__ cart_out,
                                                           int32_t* __restrict__ accept_out, int64_t* __restrict__ result,
-                                                          int64_t* __restrict__ next_ids_out, int32_t* __restrict__ n_acc_out) {
+                                                          int64_t* __restrict__ next_ids_out, int32_t* __restrict__ n_acc_out,
+                                                          int64_t* __restrict__ last_idx_out, int64_t* __restrict__ hid_idx0_out,
+                                                          int n0, int32_t* __restrict__ len_cur, int32_t* __restrict__ len_nxt) {
   extern __shared__ int64_t tok[];  // [n_nodes]
   const int b = blockIdx.x, lane = threadIdx.x;
   const int64_t* fl = flat_ids + (int64_t)b * flat_bstride;
@@ -99,6 +101,18 @@ __global__ __launch_bounds__(64) void greedy_accept_kernel(const int64_t* __rest
       }
     }
     if (n_acc_out) n_acc_out[b] = best_len + 1;
+    // draft-side state of the next cycle (all device resident, no host round trip):
+    //   last_idx = row of the last valid catch-up row in the [B*W] padded layout,
+    //   hid_idx0 = that row repeated for the n0 depth-1 nodes,
+    //   len_cur  = draft-cache rows before the catch-up forward, len_nxt = after it.
+    const int64_t last = (int64_t)b * W + best_len;
+    if (last_idx_out) last_idx_out[b] = last;
+    if (hid_idx0_out) for (int j = 0; j < n0; ++j) hid_idx0_out[(int64_t)b * n0 + j] = last;
+    if (len_cur && len_nxt) {
+      const int32_t l = len_nxt[b];
+      len_cur[b] = l;
+      len_nxt[b] = l + best_len + 1;
+    }
   }
 }
 
@@ -106,12 +120,13 @@ extern "C" int eagle_greedy_accept(const int64_t* root_token, const int64_t* fla
                                    const int64_t* tree_indices, int n_nodes, const int64_t* retrieve, int P, int W,
                                    const int64_t* target_argmax, const int32_t* prev_len, int64_t* tree_tok_out,
                                    int64_t* cart_out, int32_t* accept_out, int64_t* result, int64_t* next_ids_out,
-                                   int32_t* n_acc_out, int B, hipStream_t stream) {
+                                   int32_t* n_acc_out, int64_t* last_idx_out, int64_t* hid_idx0_out, int n0,
+                                   int32_t* len_cur, int32_t* len_nxt, int B, hipStream_t stream) {
   if (!root_token || !flat_ids || !tree_indices || !retrieve || !target_argmax || !result) return EAGLE_ERR_ARG;
   if (n_nodes < 1 || n_nodes > 4096 || P < 1 || P >= (1 << 20) || W < 1 || B < 1) return EAGLE_ERR_SHAPE;
   hipLaunchKernelGGL(greedy_accept_kernel, dim3(B), dim3(64), (size_t)n_nodes * 8, stream, root_token, flat_ids,
                      flat_batch_stride, tree_indices, n_nodes, retrieve, P, W, target_argmax, prev_len, tree_tok_out,
-                     cart_out, accept_out, result, next_ids_out, n_acc_out);
+                     cart_out, accept_out, result, next_ids_out, n_acc_out, last_idx_out, hid_idx0_out, n0, len_cur, len_nxt);
   return eagle_check_launch();
 }
 
@@ -169,8 +184,13 @@ extern "C" int eagle_kv_compact_bf16(void* cache, int64_t n_slabs, int64_t slab_
 // the accepted path's hidden states for the next draft cycle).
 __global__ __launch_bounds__(256) void gather_accepted_kernel(const bf16_t* __restrict__ src, int n_nodes, int D,
                                                               const int64_t* __restrict__ retrieve, int W,
-                                                              const int64_t* __restrict__ result, bf16_t* __restrict__ out) {
+                                                              const int64_t* __restrict__ result, bf16_t* __restrict__ out,
+                                                              int64_t* __restrict__ root_io, int32_t* __restrict__ prev_len_io) {
   const int b = blockIdx.y, j = blockIdx.x;
+  if (j == 0 && threadIdx.x == 0) {  // verifier-side state for the next cycle
+    if (root_io) root_io[b] = result[(int64_t)b * 4 + 2];
+    if (prev_len_io) prev_len_io[b] = (int32_t)result[(int64_t)b * 4 + 3];
+  }
   const int best = (int)result[(int64_t)b * 4 + 0], alen = (int)result[(int64_t)b * 4 + 1];
   const int64_t node = retrieve[(int64_t)best * W + j];
   const bool live = j <= alen && node >= 0 && node < n_nodes;
@@ -180,10 +200,11 @@ __global__ __launch_bounds__(256) void gather_accepted_kernel(const bf16_t* __re
 }
 
 extern "C" int eagle_gather_accepted_bf16(const void* src, int n_nodes, int D, const int64_t* retrieve, int W,
-                                          const int64_t* result, void* out, int B, hipStream_t stream) {
+                                          const int64_t* result, void* out, int64_t* root_io, int32_t* prev_len_io,
+                                          int B, hipStream_t stream) {
   if (!src || !retrieve || !result || !out) return EAGLE_ERR_ARG;
   if (n_nodes < 1 || D < 8 || (D & 7) || W < 1 || B < 1) return EAGLE_ERR_SHAPE;
   hipLaunchKernelGGL(gather_accepted_kernel, dim3(W, B), dim3(256), 0, stream, (const bf16_t*)src, n_nodes, D, retrieve, W,
-                     result, (bf16_t*)out);
+                     result, (bf16_t*)out, root_io, prev_len_io);
   return eagle_check_launch();
 }

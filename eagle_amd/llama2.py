@@ -156,6 +156,19 @@ class Llama2Model(nn.Module):
             self._packed[li] = hit
         return hit[1]
 
+    def _folded_mlp(self, li: int):
+        """gate/up weights with post_attention_layernorm.weight folded into their columns
+        (W' = W * w[None, :]); rebuilt when a source parameter changes."""
+        layer = self.layers[li]
+        srcs = (layer.mlp.gate_proj.weight, layer.mlp.up_proj.weight, layer.post_attention_layernorm.weight)
+        key = tuple((w.data_ptr(), w._version) for w in srcs)
+        hit = self._packed.get(("mlp", li))
+        if hit is None or hit[0] != key:
+            w = srcs[2].detach()[None, :]
+            hit = (key, (srcs[0].detach() * w).contiguous(), (srcs[1].detach() * w).contiguous())
+            self._packed[("mlp", li)] = hit
+        return hit[1], hit[2]
+
     def _cache_for(self, li: int, B: int, need: int, device, past) -> _LayerCache:
         H, HK, hd = self._dims()
         while len(self._caches) <= li:
@@ -180,12 +193,20 @@ class Llama2Model(nn.Module):
         return c
 
     # ------------------------------------------------------------------ kernel chain
+    def _attn_workspace(self, B, H, max_kv, dev):
+        need = ops.query("eagle_attn_decode_workspace_bytes", B, H, max_kv)
+        ws = getattr(self, "_attn_ws", None)
+        if ws is None or ws.numel() < need or ws.device != dev:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            self._attn_ws = ws
+        return ws
+
     def _forward_rows(self, emb_idx, hid, hid_idx, M, B, q_len, pos, past_dev, max_kv, tmask, pad, caches,
-                      past_host=None, past_off0=0):
+                      past_host=None, past_off0=0, pos_off=0, pos_stride=1, emb_ind=None, emb_bstride=0):
         """One draft-head forward over M = B*q_len rows, all in HIP kernels.
 
         emb_idx [M] int64 rows of embed_tokens; hid [*, D] with optional row gather hid_idx [M];
-        pos [M] int64; past_dev [B] int32 device lengths (+ static offset past_off0 + chunk offset);
+        pos [M] int64 or None (then position = past + pos_off + m*pos_stride); past_dev [B] int32 device lengths (+ static offset past_off0 + chunk offset);
         max_kv: static upper bound on past+q_len when lengths live on the device only
         (``past_host`` None), else derived from the host length."""
         dev = hid.device
@@ -197,21 +218,25 @@ class Llama2Model(nn.Module):
         if emb_w.dtype != torch.bfloat16:
             raise TypeError("embed_tokens must be bf16 (cast the model with .to(torch.bfloat16))")
         # fc(cat(embed_tokens(ids), hidden)) -- eagle/llama2.py:515, :537-542
-        x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M)
+        x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
+                              ind0=emb_ind, idx0_bstride=emb_bstride)
         for li, layer in enumerate(self.layers):
             a = layer.self_attn
             cache = caches[li]
             xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
             qkv = ops.linear_skinny(xin, self._packed_weights(li))
             attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
+            ws = self._attn_workspace(B, H, (past_host + q_len) if past_host is not None else max_kv, dev)
             for r0 in range(0, q_len, 16):
                 mq = min(16, q_len - r0)
                 bound = (past_host + r0 + mq) if past_host is not None else max_kv
-                ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, past_off0 + r0, tmask, pad, attn, self._err,
-                                   B, mq, H, HK, hd, bound, True, q_len, r0)
+                ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, past_off0 + r0, tmask, pad, attn, ws,
+                                   self._err, B, mq, H, HK, hd, bound, True, q_len, r0, pos_off, pos_stride)
             x = ops.linear_skinny(attn, a.o_proj.weight, res=x)
-            xn = ops.rmsnorm(x, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
-            act = ops.linear_skinny(xn, layer.mlp.gate_proj.weight, W2=layer.mlp.up_proj.weight)
+            # post_attention_layernorm fused into the gate/up projection: the norm weight is folded
+            # into the weight columns, the row scale rsqrt(mean(x^2)+eps) is computed in-kernel
+            wg, wu = self._folded_mlp(li)
+            act = ops.linear_skinny(x, wg, W2=wu, norm_eps=layer.post_attention_layernorm.variance_epsilon)
             x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x)
         return x
 

@@ -28,8 +28,11 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
                   res: Optional[torch.Tensor] = None, W2: Optional[torch.Tensor] = None,
                   idx0: Optional[torch.Tensor] = None, x1: Optional[torch.Tensor] = None,
                   idx1: Optional[torch.Tensor] = None, M: Optional[int] = None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M,N] = epi(cat(x[idx0], x1[idx1]) @ W^T).  x [*, K0] row-major; W [N, K]."""
+                  out: Optional[torch.Tensor] = None, ind0: Optional[torch.Tensor] = None,
+                  idx0_bstride: int = 0, norm_eps: float = 0.0) -> torch.Tensor:
+    """out[M,N] = epi(cat(x[idx0], x1[idx1]) @ W^T).  x [*, K0] row-major; W [N, K].
+    ind0: double indirection for x rows (see include/eagle_hip.h); norm_eps > 0 fuses the RMSNorm
+    row scale (W must then carry the norm weight folded into its columns)."""
     _chk(x, "x"), _chk(W, "W")
     N, K = W.shape
     K0 = x.shape[-1]
@@ -43,13 +46,14 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
         M = idx0.numel() if idx0 is not None else x.shape[0]
     if x.stride(-1) != 1 or W.stride(1) != 1 or W.stride(0) != K:
         raise ValueError("x rows and W must be contiguous along K")
-    for i in (idx0, idx1):
-        if i is not None and (i.dtype != torch.int64 or not i.is_contiguous()):
+    for i in (idx0, idx1, ind0):
+        if i is not None and (i.dtype != torch.int64 or (not i.is_contiguous() and not (i is idx0 and ind0 is not None))):
             raise TypeError("row index arrays must be contiguous int64")
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=x.device)
     epi = EPI_SILU_MUL if W2 is not None else EPI_LINEAR
     call("eagle_gemm_skinny_bf16", ptr(x), ptr(idx0), x.stride(0) if x.dim() > 1 else K0, K0,
+         ptr(ind0), (ind0.numel() if ind0 is not None else 0), idx0_bstride, float(norm_eps),
          ptr(x1), ptr(idx1), (x1.stride(0) if x1 is not None else 0),
          ptr(W), ptr(W2), ptr(bias), ptr(res), (res.stride(0) if res is not None else 0),
          ptr(out), out.stride(0), M, N, K, epi, stream())
@@ -69,11 +73,12 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, want_rstd: bool = Fals
     return (y, rstd) if want_rstd else y
 
 
-def tree_attention(qkv: torch.Tensor, position_ids: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+def tree_attention(qkv: torch.Tensor, position_ids: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
                    kcache: torch.Tensor, vcache: torch.Tensor, past_len: torch.Tensor, past_off: int,
                    tree_mask: Optional[torch.Tensor], pad_mask: Optional[torch.Tensor], out: torch.Tensor,
-                   err_flag: Optional[torch.Tensor], B: int, M: int, H: int, HK: int, hd: int, max_kv: int,
-                   causal: bool, rows_per_req: int, row_off: int) -> None:
+                   workspace: torch.Tensor, err_flag: Optional[torch.Tensor], B: int, M: int, H: int, HK: int, hd: int,
+                   max_kv: int, causal: bool, rows_per_req: int, row_off: int, pos_off: int = 0,
+                   pos_stride: int = 1) -> None:
     """See include/eagle_hip.h: eagle_tree_attention_bf16."""
     _chk(qkv, "qkv"), _chk(kcache, "kcache"), _chk(vcache, "vcache"), _chk(out, "out")
     cap = kcache.shape[2]
@@ -85,10 +90,13 @@ def tree_attention(qkv: torch.Tensor, position_ids: torch.Tensor, cos: torch.Ten
         tmb = tree_mask.stride(0) if tree_mask.dim() == 3 else 0
     if pad_mask is not None and (pad_mask.dtype != torch.uint8 or pad_mask.stride(-1) != 1):
         raise TypeError("pad_mask must be uint8 [B, kv]")
-    call("eagle_tree_attention_bf16", ptr(qkv), qkv.stride(0), ptr(position_ids), ptr(cos), ptr(sin), cos.shape[0],
-         ptr(kcache), ptr(vcache), kcache.stride(0), cap, ptr(past_len), past_off,
+    if workspace.numel() * workspace.element_size() < query("eagle_attn_decode_workspace_bytes", B, H, max_kv):
+        raise ValueError("attention workspace too small")
+    call("eagle_tree_attention_bf16", ptr(qkv), qkv.stride(0), ptr(position_ids), pos_off, pos_stride,
+         ptr(cos), ptr(sin), cos.shape[0], ptr(kcache), ptr(vcache), kcache.stride(0), cap, ptr(past_len), past_off,
          ptr(tree_mask), T, tmb, ptr(pad_mask), (pad_mask.stride(0) if pad_mask is not None else 0),
-         ptr(out), out.stride(0), ptr(err_flag), B, M, H, HK, hd, max_kv, int(causal), rows_per_req, row_off, stream())
+         ptr(out), out.stride(0), ptr(workspace), ptr(err_flag), B, M, H, HK, hd, max_kv, int(causal), rows_per_req,
+         row_off, stream())
 
 
 _ws_cache = {}
@@ -150,7 +158,9 @@ def tree_gather_ids(flat_ids: torch.Tensor, tree_idx: torch.Tensor, B: int = 1, 
 def greedy_accept(root_token: torch.Tensor, flat_ids: torch.Tensor, tree_indices: torch.Tensor,
                   retrieve: torch.Tensor, target_argmax: torch.Tensor, prev_len: Optional[torch.Tensor],
                   B: int = 1, want_debug: bool = False, next_ids: Optional[torch.Tensor] = None,
-                  n_acc: Optional[torch.Tensor] = None, result: Optional[torch.Tensor] = None):
+                  n_acc: Optional[torch.Tensor] = None, result: Optional[torch.Tensor] = None,
+                  last_idx: Optional[torch.Tensor] = None, hid_idx0: Optional[torch.Tensor] = None,
+                  len_cur: Optional[torch.Tensor] = None, len_nxt: Optional[torch.Tensor] = None):
     """result [B,4] int64 = {best_path, accept_length, next_token, new_len}."""
     n_nodes = tree_indices.numel()
     P_, W = retrieve.shape
@@ -165,6 +175,7 @@ def greedy_accept(root_token: torch.Tensor, flat_ids: torch.Tensor, tree_indices
         acc = torch.empty((B, P_), dtype=torch.int32, device=dev)
     call("eagle_greedy_accept", ptr(root_token), ptr(flat), flat.stride(0), ptr(tree_indices), n_nodes,
          ptr(retrieve), P_, W, ptr(target_argmax), ptr(prev_len), ptr(tok), ptr(cart), ptr(acc), ptr(result), ptr(next_ids), ptr(n_acc),
+         ptr(last_idx), ptr(hid_idx0), (hid_idx0.numel() // B if hid_idx0 is not None else 0), ptr(len_cur), ptr(len_nxt),
          B, stream())
     return (result, tok, cart, acc) if want_debug else result
 
@@ -181,12 +192,16 @@ def kv_compact(cache: torch.Tensor, B: int, inner: int, retrieve: torch.Tensor, 
          ptr(result), ptr(prev_len), cap, ptr(err_flag), stream())
 
 
-def gather_accepted(src: torch.Tensor, retrieve: torch.Tensor, result: torch.Tensor, B: int = 1) -> torch.Tensor:
+def gather_accepted(src: torch.Tensor, retrieve: torch.Tensor, result: torch.Tensor, B: int = 1,
+                    root_io: Optional[torch.Tensor] = None, prev_len_io: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(src, "src")
     n_nodes, D = src.shape[-2], src.shape[-1]
     W = retrieve.shape[1]
-    out = torch.empty((B, W, D), dtype=BF16, device=src.device)
-    call("eagle_gather_accepted_bf16", ptr(src), n_nodes, D, ptr(retrieve), W, ptr(result), ptr(out), B, stream())
+    if out is None:
+        out = torch.empty((B, W, D), dtype=BF16, device=src.device)
+    call("eagle_gather_accepted_bf16", ptr(src), n_nodes, D, ptr(retrieve), W, ptr(result), ptr(out), ptr(root_io),
+         ptr(prev_len_io), B, stream())
     return out
 
 

@@ -16,7 +16,8 @@ Per cycle, for each of B independent requests:
              tree-masked forward at position stable_len + d, lm_head, top-k -> flat rows 1..
   verify     first-argmax of the verifier's logits per tree node, greedy acceptance along the
              root->leaf paths, in-place compaction of the verifier's KV cache, gather of the
-             accepted hidden states and of the tokens that follow them.
+             accepted hidden states and of the tokens that follow them.  ``verify`` also advances
+             the draft-side lengths, so exactly one ``draft`` must follow each ``verify``.
 The verifier forward itself is out of scope: its logits, hidden states
 and KV cache are inputs.
 """
@@ -48,12 +49,16 @@ class EagleDrafter:
         self.R = 1 + self.n_fwd                              # flat top-k rows per request
         self.cap = (max_ctx + self.W + self.n_fwd + 255) // 256 * 256
         self.dev, self.D = dev, model.config.hidden_size
+        # static bound on stable_len + tree rows handed to the attention launcher (grid size); a caller
+        # that knows a tighter bound for the coming cycles may lower it (must stay >= the true length)
+        self.kv_bound = self.cap
         B, V = batch, lm_head_weight.shape[0]
         self.caches = [model._cache_for(li, B, self.cap, dev, None) for li in range(len(model.layers))]
-        self.stable_len = torch.zeros(B, dtype=torch.int32, device=dev)  # final rows of the draft KV cache
+        # draft KV-cache lengths: len_cur = rows before the catch-up forward, len_nxt = after it
+        self.len_cur = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.len_nxt = torch.zeros(B, dtype=torch.int32, device=dev)
         self.flat_ids = torch.zeros((B, self.R, topk), dtype=torch.int64, device=dev)
         self.flat_vals = torch.zeros((B, self.R, topk), dtype=BF16, device=dev)
-        self._arW = torch.arange(self.W, dtype=torch.int64, device=dev)
         self._rowbase = torch.arange(B, dtype=torch.int64, device=dev) * self.W
         rows_max = B * max(self.W, self.tb.n_nodes, 16)
         self._ws = torch.empty(ops.query("eagle_topk_workspace_bytes", rows_max, V, topk), dtype=torch.uint8, device=dev)
@@ -62,13 +67,23 @@ class EagleDrafter:
         for s in self.tb.steps:                               # static batch-major parent-row gathers
             self._hid_idx.append((ar_b * prev_n + s.parent_row[None, :]).reshape(-1).contiguous())
             prev_n = len(s.nodes)
-        # verify-side outputs (persistent so a captured graph can be replayed)
+        self.n0 = len(self.tb.steps[0].nodes)
+        # state handed from verify() to the next draft() (persistent: a captured graph replays it)
         self.result = torch.zeros((B, 4), dtype=torch.int64, device=dev)
         self.next_ids = torch.zeros((B, self.W), dtype=torch.int64, device=dev)
         self.n_acc = torch.ones(B, dtype=torch.int32, device=dev)
+        self.last_idx = torch.zeros(B, dtype=torch.int64, device=dev)          # last valid catch-up row
+        self.hid_idx0 = torch.zeros(B * self.n0, dtype=torch.int64, device=dev)  # ... repeated per depth-1 node
+        self.acc_hidden = torch.zeros((B, self.W, self.D), dtype=BF16, device=dev)
+
+    @property
+    def stable_len(self) -> torch.Tensor:
+        """Final (non-speculative) rows of the draft KV cache, per request."""
+        return self.len_nxt
 
     def reset(self):
-        self.stable_len.zero_()
+        self.len_cur.zero_()
+        self.len_nxt.zero_()
 
     # -------------------------------------------------------------- draft side
     def _head_topk(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int, row0: int, n: int):
@@ -90,43 +105,50 @@ class EagleDrafter:
         assert B == self.B and input_ids.shape[1] == ctx + 1
         m = self.model
         ids = input_ids[:, 1:].reshape(-1).contiguous()
-        pos = torch.arange(ctx, dtype=torch.int64, device=self.dev).repeat(B)
-        self.stable_len.zero_()
-        x = m._forward_rows(ids, hidden.reshape(B * ctx, D).contiguous(), None, B * ctx, B, ctx, pos, self.stable_len,
+        self.len_cur.zero_()
+        x = m._forward_rows(ids, hidden.reshape(B * ctx, D).contiguous(), None, B * ctx, B, ctx, None, self.len_cur,
                             None, None, None, self.caches, past_host=0)
-        self.stable_len.fill_(ctx)
+        self.len_nxt.fill_(ctx)
         last = torch.arange(B, dtype=torch.int64, device=self.dev) * ctx + (ctx - 1)
         self._head_topk(x, last, B, 0, 1)
-        self._expand(x, last)
+        self._expand(x, last[:, None].expand(B, self.n0).reshape(-1).contiguous())
         return self.flat_ids, self.flat_vals
 
-    def draft(self, acc_hidden: torch.Tensor, acc_ids: torch.Tensor, n_acc: torch.Tensor):
+    def set_accepted(self, n_acc: torch.Tensor):
+        """Host-free state update for callers that do not go through ``verify``: n_acc [B] int32."""
+        self.len_cur.copy_(self.len_nxt)
+        self.len_nxt += n_acc
+        self.last_idx.copy_(self._rowbase + (n_acc.long() - 1))
+        self.hid_idx0.copy_(self.last_idx[:, None].expand(self.B, self.n0).reshape(-1))
+
+    def draft(self, acc_hidden: torch.Tensor, acc_ids: torch.Tensor, n_acc: Optional[torch.Tensor] = None):
         """One expansion.  acc_hidden [B,W,D] bf16 / acc_ids [B,W] int64 hold, per request, the
-        verifier hidden states of the n_acc[b] (device int32, 1..W) newly accepted tokens and the
-        token that FOLLOWS each of them (the draft head pairs hidden[i] with token[i+1]); rows
-        >= n_acc are padding.  Advances the stable length by n_acc.
+        verifier hidden states of the newly accepted tokens and the token that FOLLOWS each of
+        them (the draft head pairs hidden[i] with token[i+1]); rows beyond the accepted count are
+        padding.  The accepted count comes from the preceding ``verify`` (device state) or, when
+        given, from n_acc [B] (device int32, 1..W).  Advances the stable length by it.
         Returns (flat_ids [B,R,k], flat_vals [B,R,k]) -- persistent buffers."""
         B, W, D, m = self.B, self.W, self.D, self.model
-        pos = (self.stable_len.long()[:, None] + self._arW[None, :]).reshape(-1)
-        x = m._forward_rows(acc_ids.reshape(-1), acc_hidden.reshape(B * W, D), None, B * W, B, W, pos,
-                            self.stable_len, self.cap, None, None, self.caches)
-        last = self._rowbase + (n_acc.long() - 1)             # each request's last valid row
-        self.stable_len += n_acc
-        self._head_topk(x, last, B, 0, 1)
-        self._expand(x, last)
+        if n_acc is not None:
+            self.set_accepted(n_acc)
+        x = m._forward_rows(acc_ids.reshape(-1), acc_hidden.reshape(B * W, D), None, B * W, B, W, None,
+                            self.len_cur, self.kv_bound, None, None, self.caches)
+        self._head_topk(x, self.last_idx, B, 0, 1)
+        self._expand(x, self.hid_idx0)
         return self.flat_ids, self.flat_vals
 
-    def _expand(self, x: torch.Tensor, last: torch.Tensor):
+    def _expand(self, x: torch.Tensor, hid_idx0: torch.Tensor):
         B, m = self.B, self.model
         stride = self.R * self.k
         off, prev_row0 = 0, 0
         for d, s in enumerate(self.tb.steps):
             n = len(s.nodes)
-            ids = ops.tree_gather_ids(self.flat_ids[:, prev_row0], s.tree_indices, B=B, batch_stride=stride)
-            hid_idx = last[:, None].expand(B, n).reshape(-1).contiguous() if d == 0 else self._hid_idx[d]
-            pos = (self.stable_len.long() + d)[:, None].expand(B, n).reshape(-1).contiguous()
-            x = m._forward_rows(ids.reshape(-1), x, hid_idx, B * n, B, n, pos, self.stable_len, self.cap,
-                                s.attn_mask_u8, None, self.caches, past_off0=off)
+            # tokens = flat_topk[previous rows][tree_indices] (gathered inside the fc GEMM); hidden =
+            # parent rows of the previous forward; every node of depth d sits at position
+            # stable_len + d (the kernel adds past = stable_len + off)
+            x = m._forward_rows(self.flat_ids[:, prev_row0], x, hid_idx0 if d == 0 else self._hid_idx[d], B * n, B, n,
+                                None, self.len_nxt, self.kv_bound, s.attn_mask_u8, None, self.caches, past_off0=off,
+                                pos_off=d - off, pos_stride=0, emb_ind=s.tree_indices, emb_bstride=stride)
             self._head_topk(x, None, B * n, s.row_base, n)
             off += n
             prev_row0 = s.row_base
@@ -140,16 +162,21 @@ class EagleDrafter:
         B, n = self.B, self.tb.n_nodes
         tgt = ops.topk(target_logits.reshape(B * n, -1), 1, want_values=False, workspace=self._ws)[1].view(B, n)
         return ops.greedy_accept(root_token, self.flat_ids, self.tb.tree_indices, self.tb.retrieve_indices, tgt,
-                                 prev_len, B=B, next_ids=self.next_ids, n_acc=self.n_acc, result=self.result)
+                                 prev_len, B=B, next_ids=self.next_ids, n_acc=self.n_acc, result=self.result,
+                                 last_idx=self.last_idx, hid_idx0=self.hid_idx0, len_cur=self.len_cur,
+                                 len_nxt=self.len_nxt)
 
     def compact(self, prev_len: torch.Tensor, target_kv: Optional[torch.Tensor], target_hidden: torch.Tensor,
-                kv_inner: int = 1) -> torch.Tensor:
+                kv_inner: int = 1, root_io: Optional[torch.Tensor] = None, update_prev_len: bool = False) -> torch.Tensor:
         """In-place compaction of the verifier's KV cache ([outer, B, inner, cap, hd], the tree's rows
         at [prev_len, prev_len+n_nodes)) and gather of the accepted path's hidden states
-        [B, W, D] (zeros beyond accept_length+1) for the next ``draft``."""
+        [B, W, D] (zeros beyond accept_length+1; a persistent buffer) for the next ``draft``.
+        root_io / update_prev_len: also overwrite the caller's root-token and prev_len arrays with
+        next_token / new_len, so a serving loop needs no host round trip between cycles."""
         if target_kv is not None:
             ops.kv_compact(target_kv, self.B, kv_inner, self.tb.retrieve_indices, self.result, prev_len, self.model._err)
-        return ops.gather_accepted(target_hidden, self.tb.retrieve_indices, self.result, B=self.B)
+        return ops.gather_accepted(target_hidden, self.tb.retrieve_indices, self.result, B=self.B, root_io=root_io,
+                                   prev_len_io=prev_len if update_prev_len else None, out=self.acc_hidden)
 
     def check_errors(self):
         """Host-side look at the device error flag (sync point; not for the hot loop)."""

@@ -31,8 +31,14 @@ typedef struct ihipStream_t* eagle_stream_t; /* == hipStream_t */
  * bf16 like the eager ops.  EPI_SILU_MUL: out = silu(x.W^T) * (x.W2^T).
  * Replaces nn.Linear at draft time: fc(cat(embed_tokens(ids), hidden)) eagle/llama2.py:515,:542;
  * q/k/v/o_proj :222-224,:280; LlamaMLP :317; residual adds :385,:391; and the frozen lm_head
- * eagle/train.py:215-228 applied to draft rows. Requires K % 32 == 0, K0 % 32 == 0. */
+ * eagle/train.py:215-228 applied to draft rows. Requires K % 32 == 0, K0 % 32 == 0.
+ * ind0 != NULL: double indirection for the x0 rows, row m = idx0[(m/ind_n)*idx0_bstride + ind0[m%ind_n]]
+ * (the tree step's input_ids = flat_topk[tree_indices], SURVEY.md a20, without a gather pass).
+ * norm_eps > 0: every output row m is scaled by rsqrt(mean_k(x[m,k]^2) + norm_eps), computed from
+ * the x fragments the kernel streams anyway: with the RMSNorm weight folded into W's columns this
+ * is post_attention_layernorm fused into the gate/up projection (eagle/llama2.py:330-335, :389-390). */
 int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int K0,
+                           const int64_t* ind0, int ind_n, int64_t idx0_bstride, float norm_eps,
                            const void* x1, const int64_t* idx1, int64_t ld1,
                            const void* W, const void* W2, const void* bias,
                            const void* res, int64_t ldr, void* out, int64_t ldo,
@@ -50,27 +56,31 @@ int eagle_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const f
                            eagle_stream_t stream);
 
 /* Tree-masked decode attention fused with RoPE and the KV-cache append, M <= 16 query rows per
- * request.  qkv [B*rows_per_req, (H+2*HK)*hd] (fused q|k|v projection output; request b's query m
- * is row b*rows_per_req + row_off + m, so longer inputs are processed in 16-row chunks),
- * position_ids [B*rows_per_req],
+ * request, split over 64-key chunks (one workgroup per chunk x head x request) + a combine pass.
+ * qkv [B*rows_per_req, (H+2*HK)*hd] (fused q|k|v projection output; request b's query m is row
+ * b*rows_per_req + row_off + m, so longer inputs are processed in 16-row chunks).
+ * position_ids [B*rows_per_req] int64, or NULL: position = past + pos_off + m*pos_stride
+ * (pos_off 0 / pos_stride 1 = the reference's default arange, eagle/llama2.py:520-527;
+ * pos_stride 0 = every row at the same position, as tree steps need).
  * cos/sin tables [n_pos, hd] bf16 (the reference's cached tables cast to bf16),
  * kcache/vcache [B, HK, cap, hd] (element stride between requests = cache_batch_stride),
  * past_len [B] (device int32) + past_off = rows already in the cache; the M new roped K rows and
  * V rows are appended at [past, past+M).  tree_mask [M,T] bytes (0 = masked) overlays the last T
  * key columns (tree_mask_batch_stride 0 = shared by all requests); pad_mask [B, >= past+M] bytes
  * (0 = padded key) or NULL; causal != 0 adds the causal mask when M > 1.  out [B*rows_per_req, H*hd].
- * max_kv >= max_b(past+M) sizes the LDS score buffer (eagle_attn_decode_lds_bytes(max_kv) <= 160 KiB).
+ * max_kv >= max_b(past+M) sizes the grid and the workspace
+ * (eagle_attn_decode_workspace_bytes(B, H, max_kv) bytes of fp32 partials).
  * Device-side violations (past+M > cap or > max_kv) set *err_flag = 1 and skip the request.
  * Replaces LlamaAttention.forward after the projections, eagle/llama2.py:226-273, with the mask
  * semantics of _prepare_decoder_attention_mask :460-491 (tree overlay :482-488). */
-int64_t eagle_attn_decode_lds_bytes(int max_kv);
-int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const int64_t* position_ids,
-                              const void* cos_table, const void* sin_table, int n_pos,
+int64_t eagle_attn_decode_workspace_bytes(int B, int H, int max_kv);
+int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const int64_t* position_ids, int pos_off,
+                              int pos_stride, const void* cos_table, const void* sin_table, int n_pos,
                               void* kcache, void* vcache, int64_t cache_batch_stride, int cap,
                               const int32_t* past_len, int past_off,
                               const uint8_t* tree_mask, int T, int64_t tree_mask_batch_stride,
                               const uint8_t* pad_mask, int64_t pad_mask_stride,
-                              void* out, int64_t ld_out, int* err_flag,
+                              void* out, int64_t ld_out, void* workspace, int* err_flag,
                               int B, int M, int H, int HK, int hd, int max_kv, int causal,
                               int rows_per_req, int row_off, eagle_stream_t stream);
 
@@ -93,20 +103,27 @@ int eagle_tree_gather_ids(const int64_t* flat_ids, int64_t flat_batch_stride, co
  * next_token, prev_len[b] + accept_length + 1}; optional tree_tok_out [B,n_nodes],
  * cart_out [B,P,W], accept_out [B,P]; optional next_ids_out [B,W] = the token following each
  * accepted hidden row (accepted draft tokens, then next_token; zero padded) and n_acc_out [B] =
- * accept_length + 1: the inputs of the next draft cycle. */
+ * accept_length + 1: the inputs of the next draft cycle; optional draft-side state for that cycle:
+ * last_idx_out [B] = b*W + accept_length (last valid catch-up row), hid_idx0_out [B,n0] = the same
+ * row repeated for the n0 depth-1 nodes, and the in/out length pair len_cur/len_nxt [B] int32
+ * (len_cur = len_nxt; len_nxt += accept_length + 1). */
 int eagle_greedy_accept(const int64_t* root_token, const int64_t* flat_ids, int64_t flat_batch_stride,
                         const int64_t* tree_indices, int n_nodes, const int64_t* retrieve, int P, int W,
                         const int64_t* target_argmax, const int32_t* prev_len, int64_t* tree_tok_out,
                         int64_t* cart_out, int32_t* accept_out, int64_t* result, int64_t* next_ids_out,
-                        int32_t* n_acc_out, int B, eagle_stream_t stream);
+                        int32_t* n_acc_out, int64_t* last_idx_out, int64_t* hid_idx0_out, int n0,
+                        int32_t* len_cur, int32_t* len_nxt, int B, eagle_stream_t stream);
 /* In-place compaction of the accepted path's KV rows: cache viewed as [n_slabs][cap][row_elems]
  * with slab = (outer*B + b)*inner + i; rows prev_len[b] + retrieve[best][j] -> prev_len[b] + j. */
 int eagle_kv_compact_bf16(void* cache, int64_t n_slabs, int64_t slab_stride, int row_elems, int B,
                           int inner, const int64_t* retrieve, int W, const int64_t* result,
                           const int32_t* prev_len, int cap, int* err_flag, eagle_stream_t stream);
-/* out[b][j] = src[b][retrieve[best_b][j]] for j <= accept_length_b (zeros after). */
+/* out[b][j] = src[b][retrieve[best_b][j]] for j <= accept_length_b (zeros after).  Optional
+ * root_io [B] / prev_len_io [B]: overwritten with next_token / new_len for the next cycle (this is
+ * the last kernel of the verify chain, so earlier kernels still saw the old values). */
 int eagle_gather_accepted_bf16(const void* src, int n_nodes, int D, const int64_t* retrieve, int W,
-                               const int64_t* result, void* out, int B, eagle_stream_t stream);
+                               const int64_t* result, void* out, int64_t* root_io, int32_t* prev_len_io,
+                               int B, eagle_stream_t stream);
 
 /* Fused soft-label CE + smooth-L1 + agreement at the logits level.
  * Replaces eagle/train.py:108-123 (== eagle/train_tp.py:90-105).

@@ -25,7 +25,9 @@ def dev():
 def close(a, b, rtol=1e-2, atol=None, what=""):
     a, b = a.float().cpu(), b.float().cpu()
     scale = float(b.abs().mean()) + 1e-12
-    atol = atol if atol is not None else 2e-2 * scale
+    # default absolute floor: 2% of the mean magnitude plus one bf16 ulp (2^-8) at the largest
+    # magnitude -- the residual stream is rounded to bf16 at its own scale before cancellation
+    atol = atol if atol is not None else 2e-2 * scale + float(b.abs().max()) / 256.0
     err = (a - b).abs()
     tol = atol + rtol * b.abs()
     bad = int((err > tol).sum())
@@ -80,6 +82,34 @@ def test_gemm_skinny_gather_concat():
     y = ops.linear_skinny(emb.to(dev()), W.to(dev()), bias=bias.to(dev()), idx0=ids.to(dev()), x1=hid.to(dev()),
                           idx1=prow.to(dev()), M=M)
     close(y, ref, what="gather+concat")
+
+
+def test_gemm_skinny_double_indirection_and_fused_rmsnorm():
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(12)
+    V, D, B, n = 500, 128, 3, 4
+    emb = torch.randn(V, D, generator=g).to(BF)
+    hid = torch.randn(B * n, D, generator=g).to(BF)
+    W = (torch.randn(64, 2 * D, generator=g) / (2 * D) ** 0.5).to(BF)
+    flat = torch.randint(0, V, (B, 7, 10), generator=g)           # flat top-k table per request
+    tree_idx = torch.tensor([0, 1, 2, 10])
+    row0 = 2
+    ids = flat[:, row0:].reshape(B, -1)[:, tree_idx]             # [B, n]
+    ref = torch.cat([emb[ids.reshape(-1)], hid], -1).float() @ W.float().t()
+    fd = flat.to(dev())
+    y = ops.linear_skinny(emb.to(dev()), W.to(dev()), idx0=fd[:, row0], x1=hid.to(dev()), M=B * n,
+                          ind0=tree_idx.to(dev()), idx0_bstride=7 * 10)
+    close(y, ref, what="double indirection")
+    # fused RMSNorm: silu(norm(x) Wg^T) * (norm(x) Wu^T) with the norm weight folded into the weights
+    K, I, M = 256, 192, 5
+    x = (torch.randn(M, K, generator=g) * 2).to(BF)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF)
+    Wg = (torch.randn(I, K, generator=g) / K ** 0.5).to(BF)
+    Wu = (torch.randn(I, K, generator=g) / K ** 0.5).to(BF)
+    xn = dm.rmsnorm(x, nw, 1e-6)
+    ref = torch.nn.functional.silu((xn.float() @ Wg.float().t()).to(BF)) * (xn.float() @ Wu.float().t()).to(BF)
+    y = ops.linear_skinny(x.to(dev()), (Wg * nw[None]).to(dev()), W2=(Wu * nw[None]).to(dev()), norm_eps=1e-6)
+    close(y, ref, rtol=2e-2, what="fused rmsnorm + silu*up")
 
 
 def test_gemm_skinny_rejects_bad_shapes():
@@ -417,7 +447,7 @@ def test_drafter_cycle_matches_oracle_loop(expand):
         # --- next expansion on both sides
         tokens = torch.cat([tokens, torch.tensor([path_tokens])], dim=1)
         ids_o, vals_o, stable, _ = ot.topk_generate(draft_fn, None, tb_o, acc_h, tokens, stable, head_fn=head_fn)
-        ids_g, vals_g = drafter.draft(acc_h_g, drafter.next_ids, drafter.n_acc)
+        ids_g, vals_g = drafter.draft(acc_h_g, drafter.next_ids)
         assert torch.equal(ids_g[0].cpu(), ids_o), f"cycle {cycle}: flat top-k ids differ"
         assert torch.equal(vals_g[0].cpu(), vals_o)
         prev_len = new_len
