@@ -30,12 +30,17 @@ class HipKernelError(RuntimeError):
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, I, L, F, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
+    "eagle_gemm_nt_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, P]),
+    "eagle_transpose_bf16": (I, [P, L, P, L, I, I, P]),
     "eagle_rmsnorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),
     "eagle_rmsnorm_bwd_workspace_bytes": (L, [I, I]),
     "eagle_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, P, I, P, I, I, P]),
     "eagle_attn_decode_workspace_bytes": (L, [I, I, I]),
     "eagle_tree_attention_bf16": (I, [P, L, P, I, I, P, P, I, P, P, L, I, P, I, P, I, L, P, L, P, L, P, P,
                                       I, I, I, I, I, I, I, I, I, P]),
+    "eagle_attn_train_fwd_bf16": (I, [P, L, P, L, P, I, I, I, I, P]),
+    "eagle_attn_train_bwd_bf16": (I, [P, L, P, L, P, L, P, P, P, L, I, I, I, I, P]),
+    "eagle_rope_qk_bf16": (I, [P, L, P, P, P, I, L, I, I, I, I, P]),
     "eagle_topk_workspace_bytes": (L, [I, I, I]),
     "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P]),
     "eagle_tree_gather_ids": (I, [P, L, P, I, P, I, P]),

@@ -1,0 +1,193 @@
+// Large-M bf16 GEMM on MFMA for the training step and prompt prefill (gfx950).
+//
+//   C[M,N] = epilogue( A[M,K] . B[N,K]^T )       both operands K-contiguous ("NT"), fp32 accumulate
+//
+// Replaces the nn.Linear forward calls of eagle/llama2.py (fc :542, q/k/v/o :222-224/:280, MLP
+// :317) and of the frozen lm_head (eagle/train.py:107,:110) at training sizes, and -- with
+// transposed operands prepared by eagle_transpose_bf16 -- their autograd backward GEMMs
+// (dgrad: dX = dY . W ; wgrad: dW = dY^T . X).
+//
+// Structure: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave as 4x4
+// v_mfma_f32_16x16x32_bf16 tiles), BK = 64, operands staged HBM -> LDS with 16-byte
+// global_load_lds (no VGPR round trip), double buffered; the LDS image is XOR-swizzled on the
+// SOURCE address (LDS destination of an LDS-DMA is lane-linear) with the same involution on the
+// ds_read_b128 side, which makes the fragment reads bank-conflict free.  The weight tile is the
+// MFMA A operand and the activation tile the B operand, so each lane ends up with 4 consecutive
+// output columns of one row (8-byte bf16 / 16-byte fp32 stores).  Workgroup ids are remapped so
+// that consecutive ids on one XCD walk down M within a fixed N panel (L2 reuse of the B panel).
+#include "common.h"
+
+#define GM_BM 128
+#define GM_BN 128
+#define GM_BK 64
+#define GM_THREADS 256
+
+struct GemmArgs {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const bf16_t* bias;          // [N] or null
+  const bf16_t* res; int64_t ldr;  // [M,N] bf16 or null (added after bias, each rounded like eager ops)
+  int M, N, K;
+  int out_f32;                 // 0: bf16 C, 1: fp32 C
+  int accumulate;              // C += result (same dtype as C)
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void gm_stage(const GemmArgs& p, bf16_t* ldsA, bf16_t* ldsB, int m0, int n0, int kt, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int L = i * GM_THREADS + tid;       // 16-byte slot in the [128][8] image
+    const int row = L >> 3, slot = L & 7;
+    const int chunk = slot ^ (row & 7);
+    int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+    int rb = n0 + row; rb = rb < p.N ? rb : p.N - 1;
+    const bf16_t* ga = p.A + (int64_t)ra * p.lda + kt * GM_BK + chunk * 8;
+    const bf16_t* gb = p.B + (int64_t)rb * p.ldb + kt * GM_BK + chunk * 8;
+    bf16_t* da = ldsA + (i * GM_THREADS + wave * 64) * 8;   // wave-uniform base; HW adds lane*16
+    bf16_t* db = ldsB + (i * GM_THREADS + wave * 64) * 8;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                     (__attribute__((address_space(3))) void*)da, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+                                     (__attribute__((address_space(3))) void*)db, 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2][2][GM_BM * GM_BK];  // [buf][A|B] 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware remap: ids b, b+8, ... share an XCD; give each XCD a contiguous run of tiles,
+  // and walk M fastest inside the run so that neighbours reuse the same weight (B) panel.
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tn = wgid / p.tiles_m, tm = wgid - tn * p.tiles_m;
+  const int m0 = tm * GM_BM, n0 = tn * GM_BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / GM_BK;
+  gm_stage(p, lds[0][0], lds[0][1], m0, n0, 0, tid);
+  __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gm_stage(p, lds[cur ^ 1][0], lds[cur ^ 1][1], m0, n0, kt + 1, tid);
+    const bf16_t* la = lds[cur][0];
+    const bf16_t* lb = lds[cur][1];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 xf[4], wf[4];
+      const int c = 4 * s + g;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ra = wm * 64 + i * 16 + r16;
+        const int rb = wn * 64 + i * 16 + r16;
+        xf[i] = *reinterpret_cast<const bf16x8*>(la + ra * GM_BK + ((c ^ (ra & 7)) << 3));
+        wf[i] = *reinterpret_cast<const bf16x8*>(lb + rb * GM_BK + ((c ^ (rb & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + r16][n0 + wn*64 + j*16 + 4g + r]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + r16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + wn * 64 + j * 16 + 4 * g;
+      if (nb >= p.N) continue;
+      float y[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int n = nb + rr;
+        float v = acc[i][j][rr];
+        if (p.bias && n < p.N) v += bf2f(p.bias[n]);
+        if (p.res && n < p.N) v = rbf(v) + bf2f(p.res[(int64_t)m * p.ldr + n]);
+        y[rr] = v;
+      }
+      const bool full = (nb + 3 < p.N) && ((p.ldc & 3) == 0);
+      if (p.out_f32) {
+        float* o = (float*)p.C + (int64_t)m * p.ldc + nb;
+        if (full) {
+          float4 v = make_float4(y[0], y[1], y[2], y[3]);
+          if (p.accumulate) { const float4 old = *reinterpret_cast<const float4*>(o); v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+          *reinterpret_cast<float4*>(o) = v;
+        } else {
+          for (int rr = 0; rr < 4; ++rr) if (nb + rr < p.N) o[rr] = p.accumulate ? o[rr] + y[rr] : y[rr];
+        }
+      } else {
+        bf16_t* o = (bf16_t*)p.C + (int64_t)m * p.ldc + nb;
+        if (full) {
+          if (p.accumulate) {
+            const uint2 old = *reinterpret_cast<const uint2*>(o);
+            y[0] += lo_bf(old.x); y[1] += hi_bf(old.x); y[2] += lo_bf(old.y); y[3] += hi_bf(old.y);
+          }
+          *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+        } else {
+          for (int rr = 0; rr < 4; ++rr) if (nb + rr < p.N) o[rr] = f2bf(p.accumulate ? bf2f(o[rr]) + y[rr] : y[rr]);
+        }
+      }
+    }
+  }
+}
+
+static inline bool gm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// See include/eagle_hip.h for the contract.
+extern "C" int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                  const void* bias, const void* res, int64_t ldr, int M, int N, int K,
+                                  int out_f32, int accumulate, hipStream_t stream) {
+  if (!A || !B || !C) return EAGLE_ERR_ARG;
+  if (M < 1 || N < 1 || K < GM_BK || (K % GM_BK)) return EAGLE_ERR_SHAPE;
+  if ((lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N || (res && ldr < N)) return EAGLE_ERR_SHAPE;
+  if (!gm_al16(A) || !gm_al16(B) || !gm_al16(C)) return EAGLE_ERR_SHAPE;
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
+  a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
+  a.tiles_m = (M + GM_BM - 1) / GM_BM; a.tiles_n = (N + GM_BN - 1) / GM_BN;
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(a.tiles_m * a.tiles_n), dim3(GM_THREADS), 0, stream, a);
+  return eagle_check_launch();
+}
+
+// out[C, R] = in[R, C]^T (bf16), 64x64 tiles through LDS.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t ldi, bf16_t* __restrict__ out,
+                                                            int64_t ldo, int R, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? in[(int64_t)r * ldi + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) out[(int64_t)c * ldo + r] = tile[tx][i];
+  }
+}
+
+extern "C" int eagle_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, hipStream_t stream) {
+  if (!in || !out) return EAGLE_ERR_ARG;
+  if (R < 1 || C < 1 || ldi < C || ldo < R) return EAGLE_ERR_SHAPE;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, (const bf16_t*)in, ldi,
+                     (bf16_t*)out, ldo, R, C);
+  return eagle_check_launch();
+}

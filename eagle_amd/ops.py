@@ -60,6 +60,37 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
+def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+            out: Optional[torch.Tensor] = None, out_dtype=BF16, accumulate: bool = False) -> torch.Tensor:
+    """C[M,N] = A[M,K] @ B[N,K]^T (+bias) (+res) on the LDS-tiled MFMA kernel."""
+    _chk(A, "A"), _chk(B, "B")
+    M, K = A.shape
+    N = B.shape[0]
+    if B.shape[1] != K or A.stride(1) != 1 or B.stride(1) != 1:
+        raise ValueError("gemm_nt: A [M,K], B [N,K], both contiguous along K")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an output tensor")
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    if out.dtype not in (BF16, torch.float32) or out.stride(1) != 1:
+        raise TypeError("gemm_nt: C must be bf16 or fp32, row-major")
+    call("eagle_gemm_nt_bf16", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0), ptr(bias), ptr(res),
+         (res.stride(0) if res is not None else 0), M, N, K, int(out.dtype == torch.float32), int(accumulate), stream())
+    return out
+
+
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[C,R] = x[R,C]^T (bf16)."""
+    _chk(x, "x")
+    R, C = x.shape
+    if x.stride(1) != 1:
+        raise ValueError("transpose: rows must be contiguous")
+    if out is None:
+        out = torch.empty((C, R), dtype=BF16, device=x.device)
+    call("eagle_transpose_bf16", ptr(x), x.stride(0), ptr(out), out.stride(0), R, C, stream())
+    return out
+
+
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, want_rstd: bool = False):
     _chk(x, "x"), _chk(w, "w")
     D = x.shape[-1]
@@ -97,6 +128,35 @@ def tree_attention(qkv: torch.Tensor, position_ids: Optional[torch.Tensor], cos:
          ptr(tree_mask), T, tmb, ptr(pad_mask), (pad_mask.stride(0) if pad_mask is not None else 0),
          ptr(out), out.stride(0), ptr(workspace), ptr(err_flag), B, M, H, HK, hd, max_kv, int(causal), rows_per_req,
          row_off, stream())
+
+
+def rope_qk_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, L: int, n_heads_qk: int, hd: int,
+             position_ids: Optional[torch.Tensor] = None, inverse: bool = False) -> torch.Tensor:
+    """In-place RoPE on the q|k sections of qkv [rows, >= n_heads_qk*hd]."""
+    _chk(qkv, "qkv")
+    call("eagle_rope_qk_bf16", ptr(qkv), qkv.stride(0), ptr(position_ids), ptr(cos), ptr(sin), cos.shape[0],
+         qkv.shape[0], L, n_heads_qk, hd, int(inverse), stream())
+    return qkv
+
+
+def attn_train_fwd(qkv: torch.Tensor, B: int, L: int, H: int, hd: int):
+    """Causal flash attention over roped qkv [B*L, 3*H*hd] -> (out [B*L, H*hd] bf16, lse [B,H,L] fp32)."""
+    _chk(qkv, "qkv")
+    out = torch.empty((B * L, H * hd), dtype=BF16, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    call("eagle_attn_train_fwd_bf16", ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(lse), B, L, H, hd, stream())
+    return out, lse
+
+
+def attn_train_bwd(qkv: torch.Tensor, out: torch.Tensor, dout: torch.Tensor, lse: torch.Tensor, B: int, L: int, H: int,
+                   hd: int, dqkv: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(qkv, "qkv"), _chk(out, "out"), _chk(dout, "dout")
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
+    delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    call("eagle_attn_train_bwd_bf16", ptr(qkv), qkv.stride(0), ptr(out), out.stride(0), ptr(dout), dout.stride(0),
+         ptr(lse), ptr(delta), ptr(dqkv), dqkv.stride(0), B, L, H, hd, stream())
+    return dqkv
 
 
 _ws_cache = {}

@@ -44,6 +44,19 @@ int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int
                            const void* res, int64_t ldr, void* out, int64_t ldo,
                            int M, int N, int K, int epi, eagle_stream_t stream);
 
+/* C[M,N] = epilogue(A[M,K] . B[N,K]^T): LDS-tiled MFMA GEMM (128x128x64 tiles, LDS-DMA staging)
+ * for training-size M.  (+bias[N]) (+res[M,N] bf16); C is bf16 (out_f32 = 0) or fp32 (1);
+ * accumulate != 0: C += result.  K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned bases.
+ * Replaces the nn.Linear forward GEMMs of eagle/llama2.py:222-224,:280,:317,:542 and of the frozen
+ * lm_head (eagle/train.py:107,:110) at training sizes, and (with eagle_transpose_bf16 on the
+ * operands) their autograd backward GEMMs behind loss.backward() (eagle/train.py:126). */
+int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                       const void* bias, const void* res, int64_t ldr, int M, int N, int K,
+                       int out_f32, int accumulate, eagle_stream_t stream);
+/* out[C,R] = in[R,C]^T, bf16 (operand preparation for the dgrad / wgrad GEMMs). */
+int eagle_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C,
+                         eagle_stream_t stream);
+
 /* y = w * bf16(x * rsqrt(mean(x^2) + eps)); optional rstd_out[N] (fp32) for the backward.
  * Replaces LlamaRMSNorm.forward, eagle/llama2.py:330-335. D % 8 == 0, D <= 8192. */
 int eagle_rmsnorm_fwd_bf16(const void* x, const void* w, void* y, float* rstd_out, int N, int D,
@@ -83,6 +96,23 @@ int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const int64_t* po
                               void* out, int64_t ld_out, void* workspace, int* err_flag,
                               int B, int M, int H, int HK, int hd, int max_kv, int causal,
                               int rows_per_req, int row_off, eagle_stream_t stream);
+
+/* Training attention (causal, no cache, no padding mask -- eagle/train.py:105 passes no
+ * attention_mask), flash-style on MFMA; hd = 128.  qkv [B*L, 3*H*hd] = q|k|v sections with RoPE
+ * already applied (eagle_rope_qk_bf16).  fwd: out [B*L, H*hd], lse [B,H,L] (log2 units).
+ * bwd: dqkv [B*L, 3*H*hd] (gradients w.r.t. the roped q,k and v), delta_ws [B,H,L] fp32 scratch.
+ * Replaces eagle/llama2.py:247-273 with the causal mask of :14-28 and its autograd backward. */
+int eagle_attn_train_fwd_bf16(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B,
+                              int L, int H, int hd, eagle_stream_t stream);
+int eagle_attn_train_bwd_bf16(const void* qkv, int64_t ld, const void* out, int64_t ldo, const void* dout,
+                              int64_t lddo, const float* lse, float* delta_ws, void* dqkv, int64_t lddq,
+                              int B, int L, int H, int hd, eagle_stream_t stream);
+/* In-place RoPE over the first n_heads_qk heads of every row (the q and k sections):
+ * x' = bf16(bf16(x*cos) + bf16(rotate_half(x)*sin)) at position_ids[row] (NULL: row % L);
+ * inverse != 0 applies the transposed rotation (the backward).  eagle/llama2.py:56-69. */
+int eagle_rope_qk_bf16(void* qkv, int64_t ld, const int64_t* position_ids, const void* cos_table,
+                       const void* sin_table, int n_pos, int64_t nrows, int L, int n_heads_qk, int hd,
+                       int inverse, eagle_stream_t stream);
 
 /* Per-row top-k over the vocabulary; order = value descending then index ascending (a stable
  * descending sort; -0.0 == +0.0; NaN largest).  dtype 0 = bf16 logits, 1 = fp32.  out_idx

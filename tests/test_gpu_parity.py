@@ -454,3 +454,84 @@ def test_drafter_cycle_matches_oracle_loop(expand):
         assert int(drafter.stable_len[0]) == stable[0][0].shape[2] == tokens.shape[1] - 1
     assert max(accepted_lengths) >= 2
     drafter.check_errors()
+
+
+# ------------------------------------------------------------------ large-M MFMA GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 130, 192), (2048, 4096, 4096), (300, 4096, 8192),
+                                   (64, 1000, 128), (1024, 22016, 4096)])
+def test_gemm_nt(M, N, K):
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(BF)
+    B = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    ref = A.float() @ B.float().t()
+    y = ops.gemm_nt(A.to(dev()), B.to(dev()))
+    close(y, ref, what="gemm_nt bf16 out")
+    yf = ops.gemm_nt(A.to(dev()), B.to(dev()), out_dtype=torch.float32)
+    close(yf, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="gemm_nt fp32 out")
+    bias = torch.randn(N, generator=g).to(BF)
+    res = torch.randn(M, N, generator=g).to(BF)
+    y2 = ops.gemm_nt(A.to(dev()), B.to(dev()), bias=bias.to(dev()), res=res.to(dev()))
+    close(y2, (ref + bias.float()).to(BF).float() + res.float(), what="gemm_nt bias+res")
+    acc = torch.randn(M, N, generator=g)
+    ya = ops.gemm_nt(A.to(dev()), B.to(dev()), out=acc.to(dev()).clone(), accumulate=True)
+    close(ya, acc + ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="gemm_nt accumulate fp32")
+
+
+def test_transpose():
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for R, C in [(64, 64), (300, 130), (2048, 4096), (7, 1000)]:
+        x = torch.randn(R, C, generator=g).to(BF)
+        assert torch.equal(ops.transpose(x.to(dev())).cpu(), x.t().contiguous())
+
+
+# ------------------------------------------------------------------ training attention (flash fwd/bwd) and RoPE
+@pytest.mark.parametrize("B,L,H", [(1, 64, 2), (2, 200, 3), (1, 512, 4), (1, 45, 1)])
+def test_attn_train_fwd_bwd(B, L, H):
+    from eagle_amd import ops
+    hd, D = 128, H * 128
+    g = torch.Generator().manual_seed(B * 100 + L)
+    qkv = (torch.randn(B * L, 3 * D, generator=g) * 0.7).to(BF)
+    dout = torch.randn(B * L, D, generator=g).to(BF)
+    x = qkv.float().view(B, L, 3, H, hd).requires_grad_(True)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    s = (q @ k.transpose(2, 3)) / hd ** 0.5
+    s = s + torch.full((L, L), float("-inf")).triu(1)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, D)
+    ref.backward(dout.float())
+    dref = x.grad.reshape(B * L, 3 * D)
+    d = dev()
+    out, lse = ops.attn_train_fwd(qkv.to(d), B, L, H, hd)
+    close(out, ref.detach(), what="attn fwd")
+    lse_ref = torch.logsumexp(s.detach(), -1) * 1.4426950408889634
+    close(lse, lse_ref, rtol=1e-3, atol=1e-2, what="lse")
+    dqkv = ops.attn_train_bwd(qkv.to(d), out, dout.to(d), lse, B, L, H, hd)
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        close(dqkv[:, sl], dref[:, sl], rtol=2e-2, what=name)
+
+
+def test_rope_qk_forward_and_inverse():
+    from eagle_amd import ops
+    H, hd, L, B = 3, 128, 37, 2
+    g = torch.Generator().manual_seed(8)
+    qkv = torch.randn(B * L, 3 * H * hd, generator=g).to(BF)
+    cos, sin = dm.rope_tables(hd, 64)
+    pos = torch.arange(L).repeat(B)
+    q = qkv[:, : H * hd].view(B, L, H, hd).transpose(1, 2)
+    k = qkv[:, H * hd: 2 * H * hd].view(B, L, H, hd).transpose(1, 2)
+    qe, ke = dm.apply_rope(q, k, cos.to(BF), sin.to(BF), pos.view(B, L))
+    d = dev()
+    cg, sg = ops.rope_tables(hd, 64, device=d)
+    y = ops.rope_qk_(qkv.to(d).clone(), cg, sg, L, 2 * H, hd)
+    assert torch.equal(y[:, : H * hd].cpu(), qe.transpose(1, 2).reshape(B * L, H * hd))      # same bf16 op order: exact
+    assert torch.equal(y[:, H * hd: 2 * H * hd].cpu(), ke.transpose(1, 2).reshape(B * L, H * hd))
+    assert torch.equal(y[:, 2 * H * hd:].cpu(), qkv[:, 2 * H * hd:])                            # v untouched
+    # inverse = transpose of the rotation: <R x, y> == <x, R^T y>
+    a = torch.randn(B * L, 3 * H * hd, generator=g).to(BF)
+    Ra = ops.rope_qk_(a.to(d).clone(), cg, sg, L, 2 * H, hd).float().cpu()[:, : 2 * H * hd]
+    bvec = torch.randn(B * L, 3 * H * hd, generator=g).to(BF)
+    Rtb = ops.rope_qk_(bvec.to(d).clone(), cg, sg, L, 2 * H, hd, inverse=True).float().cpu()[:, : 2 * H * hd]
+    lhs = (Ra * bvec.float()[:, : 2 * H * hd]).sum()
+    rhs = (a.float()[:, : 2 * H * hd] * Rtb).sum()
+    assert abs(float(lhs - rhs)) <= 2e-2 * abs(float(lhs)) + 1.0
