@@ -34,7 +34,7 @@ SIGNATURES = {
     "eagle_transpose_bf16": (I, [P, L, P, L, I, I, P]),
     "eagle_rmsnorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),
     "eagle_rmsnorm_bwd_workspace_bytes": (L, [I, I]),
-    "eagle_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, P, I, P, I, I, P]),
+    "eagle_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, P, P, I, P, I, I, P]),
     "eagle_attn_decode_workspace_bytes": (L, [I, I, I]),
     "eagle_tree_attention_bf16": (I, [P, L, P, I, I, P, P, I, P, P, L, I, P, I, P, I, L, P, L, P, L, P, P,
                                       I, I, I, I, I, I, I, I, I, P]),
@@ -52,6 +52,15 @@ SIGNATURES = {
     "eagle_ce_combine": (I, [P, I, I, P, P, P, P, P, P]),
     "eagle_fused_ce_smoothl1_fwd_bf16": (I, [P, P, L, I, I, P, P, I, P, P, P, P, P, P, P]),
     "eagle_ce_smoothl1_bwd_bf16": (I, [P, P, L, I, I, P, P, P, F, F, P, L, P, P, I, P, P]),
+    "eagle_embed_concat_bf16": (I, [P, P, P, L, P, I, I, I, P]),
+    "eagle_silu_mul_fwd_bf16": (I, [P, L, P, L, I, I, P]),
+    "eagle_silu_mul_bwd_bf16": (I, [P, L, P, L, P, L, I, I, P]),
+    "eagle_colsum_workspace_bytes": (L, [I, I]),
+    "eagle_colsum_bf16": (I, [P, L, I, I, P, P, I, P, P]),
+    "eagle_adamw_bf16": (I, [P, P, P, P, L, F, F, F, F, F, I, P, F, P]),
+    "eagle_grad_norm_workspace_bytes": (L, []),
+    "eagle_grad_clip_coef_bf16": (I, [P, L, F, P, P, P]),
+    "eagle_make_eagle_input_bf16": (I, [P, P, P, P, P, P, I, I, I, P]),
 }
 
 _lib = None

@@ -59,8 +59,8 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_fwd_kernel(const bf16_t*
 // one block handles ROWS_PER_BLOCK consecutive rows so the dw partials stay small.
 __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                                   const bf16_t* __restrict__ w, const float* __restrict__ rstd,
-                                                                  bf16_t* __restrict__ dx, float* __restrict__ dw_part,
-                                                                  int N, int D, int rows_per_block) {
+                                                                  const bf16_t* __restrict__ res, bf16_t* __restrict__ dx,
+                                                                  float* __restrict__ dw_part, int N, int D, int rows_per_block) {
   __shared__ float sh[4];
   const int nch = D >> 3;
   float dwacc[NORM_MAX_CHUNKS][8];
@@ -100,11 +100,14 @@ __global__ __launch_bounds__(NORM_THREADS) void rmsnorm_bwd_kernel(const bf16_t*
     for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
       const int c = threadIdx.x + i * NORM_THREADS;
       if (c < nch) {
-        uint4 o;
+        uint4 o, rv = make_uint4(0, 0, 0, 0);
+        if (res) rv = *reinterpret_cast<const uint4*>(res + row * D + c * 8);   // gradient arriving over the residual branch
+        const uint32_t* ru = reinterpret_cast<const uint32_t*>(&rv);
         uint32_t* ou = reinterpret_cast<uint32_t*>(&o);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          ou[j] = pack2bf(rs * (g[i][2 * j] - xh[i][2 * j] * dot), rs * (g[i][2 * j + 1] - xh[i][2 * j + 1] * dot));
+          ou[j] = pack2bf(rs * (g[i][2 * j] - xh[i][2 * j] * dot) + lo_bf(ru[j]),
+                          rs * (g[i][2 * j + 1] - xh[i][2 * j + 1] * dot) + hi_bf(ru[j]));
         *reinterpret_cast<uint4*>(dx + row * D + c * 8) = o;
       }
     }
@@ -143,13 +146,13 @@ extern "C" int64_t eagle_rmsnorm_bwd_workspace_bytes(int N, int D) {
   return (int64_t)((N + NORM_BWD_ROWS - 1) / NORM_BWD_ROWS) * D * sizeof(float);
 }
 
-extern "C" int eagle_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const float* rstd, void* dx,
+extern "C" int eagle_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const float* rstd, const void* res, void* dx,
                                       float* dw, int accumulate_dw, void* workspace, int N, int D, hipStream_t stream) {
   if (!dy || !x || !w || !rstd || !dx || !dw || !workspace) return EAGLE_ERR_ARG;
   if (N < 1 || D < 8 || (D & 7) || D > NORM_THREADS * 8 * NORM_MAX_CHUNKS) return EAGLE_ERR_SHAPE;
   const int nb = (N + NORM_BWD_ROWS - 1) / NORM_BWD_ROWS;
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(nb), dim3(NORM_THREADS), 0, stream, (const bf16_t*)dy, (const bf16_t*)x,
-                     (const bf16_t*)w, rstd, (bf16_t*)dx, (float*)workspace, N, D, NORM_BWD_ROWS);
+                     (const bf16_t*)w, rstd, (const bf16_t*)res, (bf16_t*)dx, (float*)workspace, N, D, NORM_BWD_ROWS);
   int rc = eagle_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, (const float*)workspace, dw, nb, D,

@@ -104,6 +104,77 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, want_rstd: bool = Fals
     return (y, rstd) if want_rstd else y
 
 
+def rmsnorm_bwd(dy, x, w, rstd, res=None, dw: Optional[torch.Tensor] = None, accumulate_dw: bool = False):
+    """(dx [N,D] bf16 (+res), dw [D] fp32) of y = w * norm(x)."""
+    N, D = x.shape
+    dx = torch.empty_like(x)
+    if dw is None:
+        dw = torch.empty(D, dtype=torch.float32, device=x.device)
+        accumulate_dw = False
+    ws = _workspace(query("eagle_rmsnorm_bwd_workspace_bytes", N, D), x.device)
+    call("eagle_rmsnorm_bwd_bf16", ptr(dy), ptr(x), ptr(w), ptr(rstd), ptr(res), ptr(dx), ptr(dw), int(accumulate_dw),
+         ptr(ws), N, D, stream())
+    return dx, dw
+
+
+def embed_concat(emb: torch.Tensor, ids: torch.Tensor, hidden: torch.Tensor) -> torch.Tensor:
+    _chk(emb, "emb"), _chk(hidden, "hidden")
+    N, D = hidden.shape
+    out = torch.empty((N, 2 * D), dtype=BF16, device=hidden.device)
+    call("eagle_embed_concat_bf16", ptr(emb), ptr(ids), ptr(hidden), hidden.stride(0), ptr(out), N, D, emb.shape[0], stream())
+    return out
+
+
+def silu_mul(gu: torch.Tensor) -> torch.Tensor:
+    _chk(gu, "gu")
+    N, I2 = gu.shape
+    act = torch.empty((N, I2 // 2), dtype=BF16, device=gu.device)
+    call("eagle_silu_mul_fwd_bf16", ptr(gu), gu.stride(0), ptr(act), act.stride(0), N, I2 // 2, stream())
+    return act
+
+
+def silu_mul_bwd(gu: torch.Tensor, dact: torch.Tensor) -> torch.Tensor:
+    N, I2 = gu.shape
+    dgu = torch.empty_like(gu)
+    call("eagle_silu_mul_bwd_bf16", ptr(gu), gu.stride(0), ptr(dact), dact.stride(0), ptr(dgu), dgu.stride(0), N, I2 // 2, stream())
+    return dgu
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """out[c] (+)= sum_n x[n,c]; out bf16 or fp32 [C]."""
+    _chk(x, "x")
+    N, C = x.shape
+    ws = _workspace(query("eagle_colsum_workspace_bytes", N, C), x.device)
+    call("eagle_colsum_bf16", ptr(x), x.stride(0), N, C, ptr(out) if out.dtype == BF16 else None,
+         ptr(out) if out.dtype == torch.float32 else None, int(accumulate), ptr(ws), stream())
+    return out
+
+
+def adamw_(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=None, clip_value=0.0):
+    call("eagle_adamw_bf16", ptr(param), ptr(grad), ptr(exp_avg), ptr(exp_avg_sq), param.numel(), float(lr), float(beta1),
+         float(beta2), float(eps), float(weight_decay), int(step), ptr(grad_scale), float(clip_value), stream())
+
+
+def grad_clip_coef(grad: torch.Tensor, max_norm: float) -> torch.Tensor:
+    """[coef, norm] fp32 on device: coef = min(1, max_norm / (||grad|| + 1e-6))."""
+    out = torch.empty(2, dtype=torch.float32, device=grad.device)
+    ws = _workspace(query("eagle_grad_norm_workspace_bytes"), grad.device)
+    call("eagle_grad_clip_coef_bf16", ptr(grad), grad.numel(), float(max_norm), ptr(out), ptr(ws), stream())
+    return out
+
+
+def make_eagle_input(hidden: torch.Tensor, ids: torch.Tensor, noise: Optional[torch.Tensor] = None):
+    """(hidden_out, target, ids_out) of eagle/train.py:256-269 for hidden [B,L,D], ids [B,L]."""
+    _chk(hidden, "hidden")
+    B, L, D = hidden.shape
+    hidden = hidden.contiguous()
+    ho, tg = torch.empty_like(hidden), torch.empty_like(hidden)
+    io = torch.empty_like(ids)
+    call("eagle_make_eagle_input_bf16", ptr(hidden), ptr(noise.contiguous() if noise is not None else None), ptr(ids.contiguous()),
+         ptr(ho), ptr(tg), ptr(io), B, L, D, stream())
+    return ho, tg, io
+
+
 def tree_attention(qkv: torch.Tensor, position_ids: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
                    kcache: torch.Tensor, vcache: torch.Tensor, past_len: torch.Tensor, past_off: int,
                    tree_mask: Optional[torch.Tensor], pad_mask: Optional[torch.Tensor], out: torch.Tensor,

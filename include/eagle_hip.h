@@ -61,10 +61,11 @@ int eagle_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, in
  * Replaces LlamaRMSNorm.forward, eagle/llama2.py:330-335. D % 8 == 0, D <= 8192. */
 int eagle_rmsnorm_fwd_bf16(const void* x, const void* w, void* y, float* rstd_out, int N, int D,
                            float eps, eagle_stream_t stream);
-/* Backward of the above (autograd of eagle/llama2.py:330-335): dx[N,D] bf16, dw[D] fp32
+/* Backward of the above (autograd of eagle/llama2.py:330-335): dx[N,D] bf16 (+ res[N,D], the
+ * gradient arriving over the residual branch of eagle/llama2.py:388-391, may be NULL), dw[D] fp32
  * (accumulate_dw != 0: dw += ...).  workspace: eagle_rmsnorm_bwd_workspace_bytes(N, D). */
 int64_t eagle_rmsnorm_bwd_workspace_bytes(int N, int D);
-int eagle_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const float* rstd, void* dx,
+int eagle_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const float* rstd, const void* res, void* dx,
                            float* dw, int accumulate_dw, void* workspace, int N, int D,
                            eagle_stream_t stream);
 
@@ -177,6 +178,37 @@ int eagle_ce_smoothl1_bwd_bf16(const void* t_logits, const void* o_logits, int64
                                const float* lse_t, const float* lse_o, const float* mask, float g_p,
                                float g_v, void* dlogits, int64_t ldd, const void* predict,
                                const void* target, int D, void* dpredict, eagle_stream_t stream);
+
+/* ---- element-wise pieces of the training step ---- */
+/* out[n] = cat(embed[ids[n]], hidden[n])  ([N, 2D]; eagle/llama2.py:515, :537-542) */
+int eagle_embed_concat_bf16(const void* emb, const int64_t* ids, const void* hidden, int64_t ldh, void* out,
+                            int N, int D, int V, eagle_stream_t stream);
+/* act = silu(g) * u for gu = [g | u] ([N, 2I]); and its backward (eagle/llama2.py:317). */
+int eagle_silu_mul_fwd_bf16(const void* gu, int64_t ld, void* act, int64_t lda, int N, int I,
+                            eagle_stream_t stream);
+int eagle_silu_mul_bwd_bf16(const void* gu, int64_t ld, const void* dact, int64_t lda, void* dgu, int64_t ldd,
+                            int N, int I, eagle_stream_t stream);
+/* out[c] (+)= sum_n x[n,c] (fc.bias gradient); workspace eagle_colsum_workspace_bytes(N, C). */
+int64_t eagle_colsum_workspace_bytes(int N, int C);
+int eagle_colsum_bf16(const void* x, int64_t ld, int N, int C, void* out_bf16, float* out_f32, int accumulate,
+                      void* workspace, eagle_stream_t stream);
+/* AdamW over a flat buffer (torch.optim.AdamW semantics, eagle/train.py:66): bf16 params and
+ * grads, fp32 moments.  grad_scale (device float, may be NULL) multiplies the gradient first
+ * (clip_grad_norm_ coefficient, eagle/train_tp.py:109); clip_value > 0 clamps each gradient
+ * element (clip_grad_value_, eagle/train.py:127). */
+int eagle_adamw_bf16(void* param, const void* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step,
+                     const float* grad_scale, float clip_value, eagle_stream_t stream);
+/* coef_and_norm[0] = min(1, max_norm/(||g||+1e-6)), [1] = ||g||; workspace
+ * eagle_grad_norm_workspace_bytes(). */
+int64_t eagle_grad_norm_workspace_bytes(void);
+int eagle_grad_clip_coef_bf16(const void* grad, int64_t n, float max_norm, float* coef_and_norm,
+                              void* workspace, eagle_stream_t stream);
+/* _make_eagle_input given the verifier's last hidden state (eagle/train.py:256-269, noise
+ * :272-275 pre-drawn, may be NULL): hidden_out = hidden + noise; target[:, :-1] = hidden_out[:, 1:],
+ * last row 0; ids_out = ids shifted left with trailing 0. */
+int eagle_make_eagle_input_bf16(const void* hidden, const void* noise, const int64_t* ids, void* hidden_out,
+                                void* target, int64_t* ids_out, int B, int L, int D, eagle_stream_t stream);
 
 #ifdef __cplusplus
 }
