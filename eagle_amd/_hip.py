@@ -60,6 +60,8 @@ SIGNATURES = {
     "eagle_adamw_bf16": (I, [P, P, P, P, L, F, F, F, F, F, I, P, F, P]),
     "eagle_grad_norm_workspace_bytes": (L, []),
     "eagle_grad_clip_coef_bf16": (I, [P, L, F, P, P, P]),
+    "eagle_clip_value_bf16": (I, [P, L, F, P]),
+    "eagle_add_f32_bf16": (I, [P, P, P, L, P]),
     "eagle_make_eagle_input_bf16": (I, [P, P, P, P, P, P, I, I, I, P]),
 }
 

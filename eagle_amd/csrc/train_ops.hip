@@ -171,6 +171,37 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const float* __restrict_
   }
 }
 
+// g = clamp(g, -c, c) in place (clip_grad_value_ between micro-batches, eagle/train.py:127)
+__global__ __launch_bounds__(256) void clip_value_kernel(bf16_t* __restrict__ g, int64_t n, float c) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  if (i + 8 <= n) {
+    float f[8];
+    ld8(g + i, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(f[j], -c), c);
+    st8(g + i, f);
+  } else {
+    for (int64_t k = i; k < n; ++k) g[k] = f2bf(fminf(fmaxf(bf2f(g[k]), -c), c));
+  }
+}
+
+// out = bf16(a_f32 + b_bf16)   (vocab-sharded loss: summed fp32 dpredict partials + smooth-L1 part)
+__global__ __launch_bounds__(256) void add_f32_bf16_kernel(const float* __restrict__ a, const bf16_t* __restrict__ b,
+                                                          bf16_t* __restrict__ out, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  if (i + 8 <= n) {
+    const float4 a0 = *reinterpret_cast<const float4*>(a + i), a1 = *reinterpret_cast<const float4*>(a + i + 4);
+    float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (b) ld8(b + i, f);
+    f[0] += a0.x; f[1] += a0.y; f[2] += a0.z; f[3] += a0.w; f[4] += a1.x; f[5] += a1.y; f[6] += a1.z; f[7] += a1.w;
+    st8(out + i, f);
+  } else {
+    for (int64_t k = i; k < n; ++k) out[k] = f2bf(a[k] + (b ? bf2f(b[k]) : 0.f));
+  }
+}
+
 // _make_eagle_input (eagle/train.py:256-269) given the verifier's last hidden state:
 //   noisy = hidden + noise ; hidden_out = noisy ; target[:, :-1] = noisy[:, 1:], last row 0 ;
 //   ids_out = ids shifted left with trailing 0.   One block per (b, l) row.
@@ -266,5 +297,23 @@ extern "C" int eagle_make_eagle_input_bf16(const void* hidden, const void* noise
   if (B < 1 || L < 1 || D < 8 || (D & 7)) return EAGLE_ERR_SHAPE;
   hipLaunchKernelGGL(make_eagle_input_kernel, dim3(B * L), dim3(256), 0, stream, (const bf16_t*)hidden, (const bf16_t*)noise, ids,
                      (bf16_t*)hidden_out, (bf16_t*)target, ids_out, L, D);
+  return eagle_check_launch();
+}
+
+extern "C" int eagle_clip_value_bf16(void* grad, int64_t n, float clip, hipStream_t stream) {
+  if (!grad) return EAGLE_ERR_ARG;
+  if (n < 1 || !(clip > 0.f) || (reinterpret_cast<uintptr_t>(grad) & 15)) return EAGLE_ERR_SHAPE;
+  const int64_t nthreads = (n + 7) / 8;
+  hipLaunchKernelGGL(clip_value_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)grad, n, clip);
+  return eagle_check_launch();
+}
+
+extern "C" int eagle_add_f32_bf16(const float* a, const void* b, void* out, int64_t n, hipStream_t stream) {
+  if (!a || !out) return EAGLE_ERR_ARG;
+  if (n < 1 || ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out)) & 15))
+    return EAGLE_ERR_SHAPE;
+  const int64_t nthreads = (n + 7) / 8;
+  hipLaunchKernelGGL(add_f32_bf16_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a, (const bf16_t*)b,
+                     (bf16_t*)out, n);
   return eagle_check_launch();
 }

@@ -163,6 +163,20 @@ def grad_clip_coef(grad: torch.Tensor, max_norm: float) -> torch.Tensor:
     return out
 
 
+def clip_value_(grad: torch.Tensor, clip: float) -> torch.Tensor:
+    _chk(grad, "grad")
+    call("eagle_clip_value_bf16", ptr(grad), grad.numel(), float(clip), stream())
+    return grad
+
+
+def add_f32_bf16(a: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """bf16(a_f32 + b_bf16), same shape."""
+    _chk(a, "a", torch.float32)
+    out = torch.empty(a.shape, dtype=BF16, device=a.device)
+    call("eagle_add_f32_bf16", ptr(a.contiguous()), ptr(b.contiguous() if b is not None else None), ptr(out), a.numel(), stream())
+    return out
+
+
 def make_eagle_input(hidden: torch.Tensor, ids: torch.Tensor, noise: Optional[torch.Tensor] = None):
     """(hidden_out, target, ids_out) of eagle/train.py:256-269 for hidden [B,L,D], ids [B,L]."""
     _chk(hidden, "hidden")

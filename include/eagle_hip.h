@@ -204,6 +204,13 @@ int eagle_adamw_bf16(void* param, const void* grad, float* exp_avg, float* exp_a
 int64_t eagle_grad_norm_workspace_bytes(void);
 int eagle_grad_clip_coef_bf16(const void* grad, int64_t n, float max_norm, float* coef_and_norm,
                               void* workspace, eagle_stream_t stream);
+/* grad = clamp(grad, -clip, clip) in place: accelerator.clip_grad_value_ between the micro-batches
+ * of one optimizer step (eagle/train.py:127).  16-byte aligned base. */
+int eagle_clip_value_bf16(void* grad, int64_t n, float clip, eagle_stream_t stream);
+/* out = bf16(a + b): a fp32 (the all-reduced partial dpredict of the vocab-sharded loss), b bf16 or
+ * NULL (the replicated smooth-L1 part).  The sharded form of the lm_head backward behind
+ * eagle/train_tp.py:105-108.  16-byte aligned bases. */
+int eagle_add_f32_bf16(const float* a, const void* b, void* out, int64_t n, eagle_stream_t stream);
 /* _make_eagle_input given the verifier's last hidden state (eagle/train.py:256-269, noise
  * :272-275 pre-drawn, may be NULL): hidden_out = hidden + noise; target[:, :-1] = hidden_out[:, 1:],
  * last row 0; ids_out = ids shifted left with trailing 0. */
