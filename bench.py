@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=6)
+    ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--plant", type=float, default=0.8, help="probability that the synthetic verifier agrees with a drafted child")
     return ap.parse_args()
 
@@ -282,13 +284,12 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, a.expand)
     if not a.no_train:
-        try:
-            from eagle_amd.train_bench import train_tokens_per_s
-            tr = train_tokens_per_s(dev, rank, world, dist)
-            if rank == 0 and tr is not None:
-                out["train"] = tr
-        except ImportError:
-            pass
+        from eagle_amd.train_bench import train_tokens_per_s
+        del drafter, ver, tgt_kv
+        torch.cuda.empty_cache()
+        tr = train_tokens_per_s(dev, rank, world, dist, steps=a.train_steps, warmup=a.train_warmup)
+        if rank == 0 and tr is not None:
+            out["train"] = tr
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -31,7 +31,7 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, I, L, F, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
     "eagle_gemm_nt_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, P]),
-    "eagle_transpose_bf16": (I, [P, L, P, L, I, I, P]),
+    "eagle_transpose_bf16": (I, [P, L, P, L, I, I, I, P]),
     "eagle_rmsnorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),
     "eagle_rmsnorm_bwd_workspace_bytes": (L, [I, I]),
     "eagle_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, P, P, I, P, I, I, P]),
@@ -61,6 +61,7 @@ SIGNATURES = {
     "eagle_grad_norm_workspace_bytes": (L, []),
     "eagle_grad_clip_coef_bf16": (I, [P, L, F, P, P, P]),
     "eagle_clip_value_bf16": (I, [P, L, F, P]),
+    "eagle_scale_bf16": (I, [P, L, P, P]),
     "eagle_add_f32_bf16": (I, [P, P, P, L, P]),
     "eagle_make_eagle_input_bf16": (I, [P, P, P, P, P, P, I, I, I, P]),
 }

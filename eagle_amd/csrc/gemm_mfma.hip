@@ -167,9 +167,10 @@ extern "C" int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   return eagle_check_launch();
 }
 
-// out[C, R] = in[R, C]^T (bf16), 64x64 tiles through LDS.
+// out[C, R_pad] = in[R, C]^T (bf16), 64x64 tiles through LDS; columns [R, R_pad) are zero-filled so
+// that the result can be a K-padded GEMM operand (wgrad over a token count that is no multiple of 64).
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, int64_t ldi, bf16_t* __restrict__ out,
-                                                            int64_t ldo, int R, int C) {
+                                                            int64_t ldo, int R, int C, int R_pad) {
   __shared__ bf16_t tile[64][66];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -180,14 +181,16 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < C && r < R) out[(int64_t)c * ldo + r] = tile[tx][i];
+    if (c < C && r < R_pad) out[(int64_t)c * ldo + r] = tile[tx][i];
   }
 }
 
-extern "C" int eagle_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, hipStream_t stream) {
+extern "C" int eagle_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int R_pad,
+                                    hipStream_t stream) {
   if (!in || !out) return EAGLE_ERR_ARG;
-  if (R < 1 || C < 1 || ldi < C || ldo < R) return EAGLE_ERR_SHAPE;
-  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, stream, (const bf16_t*)in, ldi,
-                     (bf16_t*)out, ldo, R, C);
+  if (R_pad < R) R_pad = R;
+  if (R < 1 || C < 1 || ldi < C || ldo < R_pad) return EAGLE_ERR_SHAPE;
+  hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R_pad + 63) / 64), dim3(256), 0, stream, (const bf16_t*)in, ldi,
+                     (bf16_t*)out, ldo, R, C, R_pad);
   return eagle_check_launch();
 }

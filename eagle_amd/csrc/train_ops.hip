@@ -186,6 +186,23 @@ __global__ __launch_bounds__(256) void clip_value_kernel(bf16_t* __restrict__ g,
   }
 }
 
+// g *= *scale in place (clip_grad_norm_ between micro-batches, eagle/train_tp.py:109; the
+// coefficient stays in device memory)
+__global__ __launch_bounds__(256) void scale_kernel(bf16_t* __restrict__ g, int64_t n, const float* __restrict__ scale) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (i >= n) return;
+  const float c = *scale;
+  if (i + 8 <= n) {
+    float f[8];
+    ld8(g + i, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] *= c;
+    st8(g + i, f);
+  } else {
+    for (int64_t k = i; k < n; ++k) g[k] = f2bf(bf2f(g[k]) * c);
+  }
+}
+
 // out = bf16(a_f32 + b_bf16)   (vocab-sharded loss: summed fp32 dpredict partials + smooth-L1 part)
 __global__ __launch_bounds__(256) void add_f32_bf16_kernel(const float* __restrict__ a, const bf16_t* __restrict__ b,
                                                           bf16_t* __restrict__ out, int64_t n) {
@@ -315,5 +332,13 @@ extern "C" int eagle_add_f32_bf16(const float* a, const void* b, void* out, int6
   const int64_t nthreads = (n + 7) / 8;
   hipLaunchKernelGGL(add_f32_bf16_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, a, (const bf16_t*)b,
                      (bf16_t*)out, n);
+  return eagle_check_launch();
+}
+
+extern "C" int eagle_scale_bf16(void* x, int64_t n, const float* scale, hipStream_t stream) {
+  if (!x || !scale) return EAGLE_ERR_ARG;
+  if (n < 1 || (reinterpret_cast<uintptr_t>(x) & 15)) return EAGLE_ERR_SHAPE;
+  const int64_t nthreads = (n + 7) / 8;
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)x, n, scale);
   return eagle_check_launch();
 }

@@ -79,15 +79,18 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
-def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[C,R] = x[R,C]^T (bf16)."""
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 1) -> torch.Tensor:
+    """out[C, R_pad] = x[R,C]^T (bf16); R_pad = R rounded up to ``pad_to``, the extra columns zero."""
     _chk(x, "x")
     R, C = x.shape
     if x.stride(1) != 1:
         raise ValueError("transpose: rows must be contiguous")
+    Rp = (R + pad_to - 1) // pad_to * pad_to
     if out is None:
-        out = torch.empty((C, R), dtype=BF16, device=x.device)
-    call("eagle_transpose_bf16", ptr(x), x.stride(0), ptr(out), out.stride(0), R, C, stream())
+        out = torch.empty((C, Rp), dtype=BF16, device=x.device)
+    elif tuple(out.shape) != (C, Rp) or out.stride(1) != 1:
+        raise ValueError(f"transpose: out must be [{C}, {Rp}] row-major")
+    call("eagle_transpose_bf16", ptr(x), x.stride(0), ptr(out), out.stride(0), R, C, Rp, stream())
     return out
 
 
@@ -167,6 +170,13 @@ def clip_value_(grad: torch.Tensor, clip: float) -> torch.Tensor:
     _chk(grad, "grad")
     call("eagle_clip_value_bf16", ptr(grad), grad.numel(), float(clip), stream())
     return grad
+
+
+def scale_(x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """x *= scale[0] in place (scale: fp32 device tensor)."""
+    _chk(x, "x"), _chk(scale, "scale", torch.float32)
+    call("eagle_scale_bf16", ptr(x), x.numel(), ptr(scale), stream())
+    return x
 
 
 def add_f32_bf16(a: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:

@@ -57,7 +57,10 @@ adjacent so that their stacked views cost nothing."""
 
 
 def _adjacent(ts: Sequence[torch.Tensor]) -> bool:
-    return all(a.is_contiguous() and a.data_ptr() + a.numel() * a.element_size() == b.data_ptr() for a, b in zip(ts, ts[1:]))
+    """Back to back in ONE storage (flatten_parameters lays q|k|v and gate|up out that way)."""
+    base = ts[0].untyped_storage().data_ptr()
+    return all(t.is_contiguous() and t.untyped_storage().data_ptr() == base for t in ts) and \
+        all(a.data_ptr() + a.numel() * a.element_size() == b.data_ptr() for a, b in zip(ts, ts[1:]))
 
 
 def _stack(ts: Sequence[torch.Tensor], cache: dict, key) -> torch.Tensor:
@@ -81,8 +84,8 @@ def layer_weights(model) -> LayerWeights:
         raise NotImplementedError("training attention kernel: kv_heads == heads and head_dim == 128 (both shipped configs)")
     cache = model._packed
     for p in (model.fc.weight, a.q_proj.weight, m.down_proj.weight):
-        if p.dtype != BF16 or not p.is_cuda:
-            raise TypeError("training runs in bf16 on the device (eagle/train.py --eagle-dtype bfloat16)")
+        if p.dtype != BF16:                                     # (ops.* reject non-device tensors: no CPU path)
+            raise TypeError("training runs in bf16 (eagle/train.py --eagle-dtype bfloat16)")
     return LayerWeights(
         fc_w=model.fc.weight.detach(), fc_b=None if model.fc.bias is None else model.fc.bias.detach(),
         wqkv=_stack((a.q_proj.weight, a.k_proj.weight, a.v_proj.weight), cache, "t_qkv"),
@@ -147,7 +150,8 @@ def draft_bwd(W: LayerWeights, saved, dout: torch.Tensor, B: int, L: int, H: int
     x0, x, qkv, attn, lse, h1, n, rstd, gu, act = saved
     acc = sink.accumulate
     ready = on_ready or (lambda name: None)
-    T = ops.transpose
+    def T(t):                                                     # [rows, C] -> [C, rows padded to the GEMM's K step]
+        return ops.transpose(t, pad_to=64)
     # down_proj: out = act . Wdown^T + h1
     d_act = ops.gemm_nt(dout, tc.get("wdown", W.wdown))
     doutT = T(dout)
@@ -450,12 +454,18 @@ class EagleTrainer:
                 on_ready = self._bucket_reducer(works)
             draft_bwd(W, saved, dpred, B, L, H, hd, cos, sin, sink, self._tc_versioned(), on_ready=on_ready)
             del saved
-            if i != last and self.mode == "dp" and self.clip > 0:
-                # accelerator.clip_grad_value_ after EVERY micro-batch backward (train.py:127); the last
-                # micro-batch's clip comes after the all-reduce and is fused into the AdamW kernel
-                self._wn_f32.clamp_(-self.clip, self.clip)
-                self._fold_wn()
-                ops.clip_value_(self.grad, self.clip)
+            if i != last and self.clip > 0:
+                # the reference clips after EVERY micro-batch backward; the last micro-batch's clip comes
+                # after the all-reduce and is fused into the AdamW kernel
+                if self.mode == "dp":                                       # clip_grad_value_, train.py:127
+                    self._wn_f32.clamp_(-self.clip, self.clip)
+                    self._fold_wn()
+                    ops.clip_value_(self.grad, self.clip)
+                else:                                                       # clip_grad_norm_, train_tp.py:109
+                    self._fold_wn()
+                    coef = ops.grad_clip_coef(self.grad, self.clip)
+                    ops.scale_(self.grad, coef)
+                    self._wn_f32.mul_(coef[0])
         for w in works:
             w.wait()
         self._optimizer_step()
@@ -510,9 +520,11 @@ class EagleTrainer:
 # ---------------------------------------------------------------------------------------------
 # vocab-sharded lm_head / CE (the multi-GPU form of eagle/train_tp.py's loss)
 # ---------------------------------------------------------------------------------------------
-def vocab_shard_bounds(V: int, world: int, rank: int, align: int = 8) -> Tuple[int, int]:
-    """Rows [v0, v1) of lm_head held by ``rank``: equal shards rounded up to ``align`` columns
-    (16-byte logit rows), the last rank takes what is left (151936 / 8 = 18992 exactly)."""
+def vocab_shard_bounds(V: int, world: int, rank: int, align: int = 64) -> Tuple[int, int]:
+    """Rows [v0, v1) of lm_head held by ``rank``: equal shards rounded up to ``align`` rows, the
+    last rank takes what is left.  align = 64 because the shard width is the K dimension of the
+    dpredict GEMM (eagle_gemm_nt_bf16: K % 64 == 0): V = 151936 over 8 ranks gives 7 x 19008 +
+    18880 rather than 8 x 18992."""
     per = (V + world - 1) // world
     per = (per + align - 1) // align * align
     v0 = min(V, rank * per)
@@ -537,8 +549,11 @@ class ShardedLmHeadLoss:
         t_logits = ops.gemm_nt(target, self.w)
         o_logits = ops.gemm_nt(predict, self.w)
         stats = ops.ce_partial(t_logits, o_logits, self.v0, predict, target)           # [N, 8] fp32 words
-        allst = torch.empty((self.world,) + tuple(stats.shape), dtype=stats.dtype, device=stats.device)
-        dist.all_gather_into_tensor(allst, stats, group=self.group)
+        if self.world > 1:
+            allst = torch.empty((self.world,) + tuple(stats.shape), dtype=stats.dtype, device=stats.device)
+            dist.all_gather_into_tensor(allst, stats, group=self.group)
+        else:
+            allst = stats[None]
         sums, lse_t, lse_o, _ = ops.ce_combine(allst, mask)
         if not want_grad:
             return sums, None
@@ -547,5 +562,6 @@ class ShardedLmHeadLoss:
         # partial dpredict over this rank's vocabulary slice in fp32, summed over ranks, then the
         # (replicated) smooth-L1 part is added once
         part = ops.gemm_nt(dlog, self.wt, out_dtype=torch.float32)
-        dist.all_reduce(part, group=self.group)
+        if self.world > 1:
+            dist.all_reduce(part, group=self.group)
         return sums, ops.add_f32_bf16(part, dpv)

@@ -1,0 +1,98 @@
+"""Draft-head training throughput (BASELINE.json configs[2]): Qwen3-8B-dims draft head
+(resources/eagle_config_qwen3_8b.json: D=4096, I=12288, 32 heads, V=151936), fused smooth-L1 + CE
+against a frozen lm_head, sequence 2048, one micro-batch of 1 x 2048 tokens per rank and optimizer
+step, data parallel over the ranks with one bucketed RCCL all-reduce of the flat bf16 gradient
+per step (eagle/train.py:85-131).  Synthetic verifier hidden states / ids, random-init weights.
+
+Called from bench.py on every rank (collectives inside).  Tokens/s follows eagle/train.py:140-141:
+loss-masked tokens per step / step wall time, summed over ranks.
+"""
+from __future__ import annotations
+
+import time
+from typing import Optional
+
+import torch
+
+BF16 = torch.bfloat16
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+
+
+def flops_per_token(cfg, L: int) -> float:
+    """Algorithmic flops of one training step per token (no recompute)."""
+    D, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+    layer = 2.0 * (2 * D * D + 4 * D * D + 3 * D * I)          # fc (K = 2D) + q,k,v,o + gate,up,down
+    head = 2.0 * D * V
+    attn_fwd = 4.0 * D * (L / 2.0)                             # QK^T + PV over the causal half
+    fwd = layer + 2 * head + attn_fwd
+    bwd = 2 * layer + head + 2.5 * attn_fwd                    # dgrad + wgrad; frozen lm_head: dgrad only
+    return fwd + bwd
+
+
+def train_tokens_per_s(dev, rank: int, world: int, dist, steps: int = 6, warmup: int = 2, L: int = 2048,
+                       config: str = "qwen3_8b", ga: int = 1) -> Optional[dict]:
+    from .config import DraftConfig, LLAMA2_7B_DRAFT, QWEN3_8B_DRAFT
+    from .llama2 import Llama2Model
+    from .train import EagleTrainer
+
+    cfg = DraftConfig(**(QWEN3_8B_DRAFT if config == "qwen3_8b" else LLAMA2_7B_DRAFT))
+    with torch.device("meta"):
+        model = Llama2Model(cfg)
+    model = model.to_empty(device=dev).to(BF16)
+    g = torch.Generator(device=dev).manual_seed(0)              # identical initial weights on every rank
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("layernorm.weight"):
+                p.fill_(1.0)
+            else:
+                p.copy_((torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32) * 0.02).to(BF16))
+        lm_head = (torch.randn((cfg.vocab_size, cfg.hidden_size), generator=g, device=dev, dtype=torch.float32) * 0.02).to(BF16)
+    group = dist.group.WORLD if (dist is not None and world > 1) else None
+    tr = EagleTrainer(model, lm_head, lr=2e-4, betas=(0.9, 0.95), grad_clip=0.5, num_warmup_steps=world * 10,
+                      num_training_steps=world * 1000, mode="dp", group=group, world_size=world)
+    gd = torch.Generator(device=dev).manual_seed(1000 + rank)  # different data per rank
+    D = cfg.hidden_size
+
+    def batch():
+        hid = torch.randn((1, L, D), generator=gd, device=dev, dtype=torch.float32).to(BF16)
+        noise = ((torch.rand((1, L, D), generator=gd, device=dev) - 0.5) * 0.2).to(BF16)
+        ids = torch.randint(0, cfg.vocab_size, (1, L), generator=gd, device=dev)
+        from . import ops
+        h, t, i = ops.make_eagle_input(hid, ids, noise)
+        return {"hidden_states": h, "target": t, "input_ids": i, "loss_mask": torch.ones((1, L), dtype=torch.int64, device=dev)}
+
+    pool = [[batch() for _ in range(ga)] for _ in range(2)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if group is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for s in range(warmup):
+        tr.step(pool[s % 2])
+    sync()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        out = tr.step(pool[s % 2])
+    sync()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if group is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    sums = out["sums"].cpu()
+    toks = world * ga * L * steps
+    fpt = flops_per_token(cfg, L)
+    tf = toks * fpt / dt / 1e12
+    res = {"value": toks / dt, "unit": "loss tokens/s (whole job)", "ms_per_step": dt / steps * 1e3, "n_gpus": world,
+           "config": {"workload": f"BASELINE configs[2]: {config} dims draft head training, fused smooth-L1+CE, seq {L}, "
+                                  f"micro-batch 1x{L} per GPU, GA {ga}, DP={world} (RCCL all-reduce of the flat bf16 gradient)"},
+           "dtype": "bf16", "steps": steps, "warmup": warmup,
+           "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / world / MFMA_PEAK_TFLOPS,
+                        "flops_per_token": fpt, "note": "whole training step (all kernels + all-reduce) per GPU, algorithmic flops"},
+           "last_step": {"ploss_per_token": float(sums[0] / sums[3]), "vloss_per_token": float(sums[1] / sums[3]),
+                         "accuracy": float(sums[2] / sums[3])}}
+    del tr, model, lm_head, pool
+    torch.cuda.empty_cache()
+    return res

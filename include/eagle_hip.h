@@ -53,8 +53,10 @@ int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int
 int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                        const void* bias, const void* res, int64_t ldr, int M, int N, int K,
                        int out_f32, int accumulate, eagle_stream_t stream);
-/* out[C,R] = in[R,C]^T, bf16 (operand preparation for the dgrad / wgrad GEMMs). */
-int eagle_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C,
+/* out[C,R_pad] = in[R,C]^T, bf16, columns [R, R_pad) zero-filled (R_pad < R: no padding): operand
+ * preparation for the dgrad / wgrad GEMMs behind loss.backward() (eagle/train.py:126); the zero
+ * padding lets a token count that is no multiple of 64 serve as the GEMM's K.  ldo >= R_pad. */
+int eagle_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int R_pad,
                          eagle_stream_t stream);
 
 /* y = w * bf16(x * rsqrt(mean(x^2) + eps)); optional rstd_out[N] (fp32) for the backward.
@@ -207,6 +209,10 @@ int eagle_grad_clip_coef_bf16(const void* grad, int64_t n, float max_norm, float
 /* grad = clamp(grad, -clip, clip) in place: accelerator.clip_grad_value_ between the micro-batches
  * of one optimizer step (eagle/train.py:127).  16-byte aligned base. */
 int eagle_clip_value_bf16(void* grad, int64_t n, float clip, eagle_stream_t stream);
+/* x *= *scale in place (scale: device float): torch.nn.utils.clip_grad_norm_ applied to the
+ * accumulated gradient after every micro-batch backward (eagle/train_tp.py:109) with the coefficient
+ * of eagle_grad_clip_coef_bf16.  16-byte aligned base. */
+int eagle_scale_bf16(void* x, int64_t n, const float* scale, eagle_stream_t stream);
 /* out = bf16(a + b): a fp32 (the all-reduced partial dpredict of the vocab-sharded loss), b bf16 or
  * NULL (the replicated smooth-L1 part).  The sharded form of the lm_head backward behind
  * eagle/train_tp.py:105-108.  16-byte aligned bases. */

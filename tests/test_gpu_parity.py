@@ -484,6 +484,9 @@ def test_transpose():
     for R, C in [(64, 64), (300, 130), (2048, 4096), (7, 1000)]:
         x = torch.randn(R, C, generator=g).to(BF)
         assert torch.equal(ops.transpose(x.to(dev())).cpu(), x.t().contiguous())
+        yp = ops.transpose(x.to(dev()), pad_to=64).cpu()       # zero-padded to the GEMM's K step
+        Rp = (R + 63) // 64 * 64
+        assert yp.shape == (C, Rp) and torch.equal(yp[:, :R], x.t()) and not yp[:, R:].any()
 
 
 # ------------------------------------------------------------------ training attention (flash fwd/bwd) and RoPE
