@@ -149,29 +149,56 @@ def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, pla
     return res_log[:, 0, 1].cpu().tolist(), elapsed
 
 
-def roofline_lm_head(drafter, rows, iters=40):
-    """Dominant kernel: gemm_skinny_kernel<2,1,0> = the lm_head weight stream.  Algorithmic bytes
-    per launch = V*D*2 (weights) + rows*D*2 (x) + rows*V*2 (logits write); HIP events on the
-    launch stream around `iters` back-to-back launches."""
+def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
+    """Dominant kernel: gemm_skinny_kernel<2,1,0> = the lm_head weight stream (one launch per
+    draft-tree step).  Measured IN the cycle, not back to back: `cycles` eager draft/verify cycles
+    with a HIP event pair (on the launch stream = torch's current stream) around every lm_head
+    launch, so each launch starts behind the down-projection kernel as it does in the timed region
+    (a back-to-back loop of the same launch runs ~13 % faster because consecutive launches overlap
+    their ramp and drain).  Algorithmic bytes per launch = V*D*2 (weights) + M*D*2 (x) + M*V*2
+    (logits), M = the step's row count; achieved = sum(bytes) / sum(durations).
+    `traffic`: HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape
+    (profiles/r01_lm_head_pmc.json, collected with tools/gpu_profile.sh), else null."""
     from eagle_amd import ops
     W = drafter.lm_head
     V, D = W.shape
-    x = torch.randn((rows, D), device=W.device, dtype=torch.float32).to(torch.bfloat16)
-    out = torch.empty((rows, V), device=W.device, dtype=torch.bfloat16)
-    for _ in range(5):
-        ops.linear_skinny(x, W, out=out)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.linear_skinny(x, W, out=out)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    nbytes = V * D * 2 + rows * D * 2 + rows * V * 2
-    return {"bound": "hbm", "kernel": "gemm_skinny_kernel<2,1,0> (lm_head, %d rows)" % rows,
+    real = ops.linear_skinny
+    marks = []
+
+    def probed(x, Wt, *a, **kw):
+        if Wt is not W:
+            return real(x, Wt, *a, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = real(x, Wt, *a, **kw)
+        e1.record()
+        marks.append((e0, e1, out.shape[0]))
+        return out
+
+    ops.linear_skinny = probed
+    try:
+        for c in range(cycles):
+            tl, th = ver.logits[c % ver.logits.shape[0]][None], ver.hidden[c % ver.hidden.shape[0]][None]
+            drafter.verify(root, tl, prev_len)
+            acc_h = drafter.compact(prev_len, tgt_kv, th, kv_inner=tgt_kv.shape[2], root_io=root, update_prev_len=True)
+            drafter.draft(acc_h, drafter.next_ids)
+        torch.cuda.synchronize()
+    finally:
+        ops.linear_skinny = real
+    marks = marks[len(marks) // 6:]                      # first cycles: warm-up
+    sec = sum(e0.elapsed_time(e1) for e0, e1, _ in marks) / 1e3
+    nbytes = sum(V * D * 2 + m * D * 2 + m * V * 2 for _, _, m in marks)
+    traffic = None
+    pj = os.path.join(ROOT, "profiles", "r01_lm_head_pmc.json")
+    if V == 32000 and os.path.exists(pj):
+        with open(pj) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
+    n = len(marks)
+    return {"bound": "hbm", "kernel": "gemm_skinny_kernel<2,1,0> (lm_head weight stream, 1-8 rows, in-cycle)",
             "achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": None,
-            "bytes_per_launch": nbytes, "us_per_launch": sec * 1e6}
+            "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "bytes_per_launch": nbytes / n, "us_per_launch": sec / n * 1e6, "launches_timed": n,
+            "timing": "HIP events around each in-cycle launch (eager, includes ~1-2 us of launch gap)"}
 
 
 def cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, expand, max_seconds=25.0):
@@ -280,7 +307,10 @@ def main():
     }
     if rank == 0:
         with torch.no_grad():
-            out["roofline"] = roofline_lm_head(drafter, rows=4)
+            root = prompt_tokens[:, -1].clone()
+            plen = torch.full((1,), min(a.ctx, 1500), dtype=torch.int32, device=dev)
+            drafter.prefill(prompt_hidden, prompt_tokens)
+            out["roofline"] = roofline_lm_head(drafter, ver, tgt_kv, root, plen)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, a.expand)
     if not a.no_train:

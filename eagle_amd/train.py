@@ -550,8 +550,9 @@ class ShardedLmHeadLoss:
         o_logits = ops.gemm_nt(predict, self.w)
         stats = ops.ce_partial(t_logits, o_logits, self.v0, predict, target)           # [N, 8] fp32 words
         if self.world > 1:
-            allst = torch.empty((self.world,) + tuple(stats.shape), dtype=stats.dtype, device=stats.device)
-            dist.all_gather_into_tensor(allst, stats, group=self.group)
+            allst = torch.empty((self.world * stats.shape[0], stats.shape[1]), dtype=stats.dtype, device=stats.device)
+            dist.all_gather_into_tensor(allst, stats, group=self.group)     # rank-major concatenation
+            allst = allst.view(self.world, stats.shape[0], stats.shape[1])
         else:
             allst = stats[None]
         sums, lse_t, lse_o, _ = ops.ce_combine(allst, mask)

@@ -1,6 +1,6 @@
 """Micro-benchmark of the training-size GEMMs (TFLOP/s), run on the GPU box."""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from eagle_amd import ops
 dev = torch.device('cuda:0')
 shapes = [(2048, 4096, 8192, 'fc'), (2048, 12288, 4096, 'qkv'), (2048, 4096, 4096, 'o'), (2048, 24576, 4096, 'gate|up qwen'),
