@@ -42,11 +42,11 @@ SIGNATURES = {
     "eagle_attn_train_bwd_bf16": (I, [P, L, P, L, P, L, P, P, P, L, I, I, I, I, P]),
     "eagle_rope_qk_bf16": (I, [P, L, P, P, P, I, L, I, I, I, I, P]),
     "eagle_topk_workspace_bytes": (L, [I, I, I]),
-    "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P]),
+    "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P, L, P]),
     "eagle_tree_gather_ids": (I, [P, L, P, I, P, I, P]),
-    "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, P, P, P, P, I, P, P, I, P]),
+    "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, P, P, P, P, I, P, P, P, I, P]),
     "eagle_kv_compact_bf16": (I, [P, L, L, I, I, I, P, I, P, P, I, P, P]),
-    "eagle_gather_accepted_bf16": (I, [P, I, I, P, I, P, P, P, P, I, P]),
+    "eagle_gather_accepted_bf16": (I, [P, I, I, P, I, P, P, P, P, P, I, P]),
     "eagle_ce_stat_bytes": (I, []),
     "eagle_ce_partial_bf16": (I, [P, P, L, I, I, I, P, P, I, P, P]),
     "eagle_ce_combine": (I, [P, I, I, P, P, P, P, P, P]),

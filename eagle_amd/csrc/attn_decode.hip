@@ -36,6 +36,7 @@ struct AttnDecArgs {
   int* err_flag;
   int B, M, H, HK, hd, cap, causal;
   int rows_per_req, row_off;  // row of request b, query m = b*rows_per_req + row_off + m
+  int vec16;                  // hd % 16 == 0 and every base 16-byte aligned: 16-byte phase-0 accesses
   float sqrt_hd;
 };
 
@@ -95,6 +96,64 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
   }
 
   // ---- phase 0: RoPE on q (always) and on the new k rows (if needed); append to the cache ----
+  if (p.vec16) {
+    // 8 elements (16 bytes) per thread: with hd = 128 the 16 rows x 16 chunks are one item per thread,
+    // and all of an item's loads (cos, sin, q, its rotation partner, k, partner, v) are independent
+    const int cpr = hd >> 3;
+    for (int i = t; i < AD_MAXM * cpr; i += AD_THREADS) {
+      const int m = i / cpr, d0 = (i - m * cpr) << 3;
+      uint4 qo = make_uint4(0, 0, 0, 0);
+      if (m < M) {
+        const int64_t row = (int64_t)b * p.rows_per_req + p.row_off + m;
+        int64_t ps = p.pos ? p.pos[row] : (int64_t)past + p.pos_off + (int64_t)m * p.pos_stride;
+        ps = ps < 0 ? 0 : (ps >= p.n_pos ? p.n_pos - 1 : ps);
+        const bool lo = d0 < half;
+        const int dp0 = lo ? d0 + half : d0 - half;
+        const bf16_t* qrow = p.qkv + row * p.ld_qkv + h * hd;
+        const bool kv_too = need_new || writer;
+        const bf16_t* krow = p.qkv + row * p.ld_qkv + (p.H + hk) * hd;
+        const bf16_t* vrow = p.qkv + row * p.ld_qkv + (p.H + p.HK + hk) * hd;
+        const uint4 cv = *reinterpret_cast<const uint4*>(p.cos_t + ps * hd + d0);
+        const uint4 sv = *reinterpret_cast<const uint4*>(p.sin_t + ps * hd + d0);
+        const uint4 qv = *reinterpret_cast<const uint4*>(qrow + d0);
+        const uint4 qp = *reinterpret_cast<const uint4*>(qrow + dp0);
+        uint4 kv = qo, kp = qo, vv4 = qo;
+        if (kv_too) {
+          kv = *reinterpret_cast<const uint4*>(krow + d0);
+          kp = *reinterpret_cast<const uint4*>(krow + dp0);
+          vv4 = *reinterpret_cast<const uint4*>(vrow + d0);
+        }
+        const uint32_t* cw = reinterpret_cast<const uint32_t*>(&cv);
+        const uint32_t* sw = reinterpret_cast<const uint32_t*>(&sv);
+        auto rot = [&](const uint4& a, const uint4& pr) {
+          const uint32_t* aw = reinterpret_cast<const uint32_t*>(&a);
+          const uint32_t* pw = reinterpret_cast<const uint32_t*>(&pr);
+          uint4 o;
+          uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float r0 = lo_bf(pw[j]), r1 = hi_bf(pw[j]);
+            if (lo) { r0 = -r0; r1 = -r1; }
+            const float y0 = rbf(lo_bf(aw[j]) * lo_bf(cw[j])) + rbf(r0 * lo_bf(sw[j]));
+            const float y1 = rbf(hi_bf(aw[j]) * hi_bf(cw[j])) + rbf(r1 * hi_bf(sw[j]));
+            ow[j] = pack2bf(y0, y1);
+          }
+          return o;
+        };
+        qo = rot(qv, qp);
+        if (kv_too) {
+          const uint4 ke = rot(kv, kp);
+          *reinterpret_cast<uint4*>(knew + m * AD_MAXHD + d0) = ke;
+          *reinterpret_cast<uint4*>(vnew + m * AD_MAXHD + d0) = vv4;
+          if (writer) {
+            *reinterpret_cast<uint4*>(kc + (int64_t)(past + m) * hd + d0) = ke;
+            *reinterpret_cast<uint4*>(vc + (int64_t)(past + m) * hd + d0) = vv4;
+          }
+        }
+      }
+      *reinterpret_cast<uint4*>(q_s + m * AD_MAXHD + d0) = qo;
+    }
+  } else
   for (int i = t; i < AD_MAXM * hd; i += AD_THREADS) {
     const int m = i / hd, d = i - m * hd;
     if (m < M) {
@@ -319,6 +378,9 @@ extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const 
   a.B = B; a.M = M; a.H = H; a.HK = HK; a.hd = hd; a.cap = cap; a.causal = causal;
   a.rows_per_req = rows_per_req; a.row_off = row_off;
   a.sqrt_hd = sqrtf((float)hd);
+  a.vec16 = ((hd & 15) == 0) && ((cache_batch_stride & 7) == 0) &&
+            (((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(cos_table) | reinterpret_cast<uintptr_t>(sin_table) |
+               reinterpret_cast<uintptr_t>(kcache) | reinterpret_cast<uintptr_t>(vcache)) & 15) == 0);
   hipLaunchKernelGGL(attn_split_kernel, dim3(a.max_splits, H, B), dim3(AD_THREADS), 0, stream, a);
   int rc = eagle_check_launch();
   if (rc) return rc;

@@ -15,6 +15,7 @@
 //   * the activation row can be the concatenation of two gathered sources:
 //     fc(cat(embed_tokens[ids], hidden[parent_row]))  (eagle/llama2.py:515, :542).
 #include "common.h"
+#include <stdlib.h>
 
 #define SK_WAVES 8
 #define EPI_LINEAR 0     // (+bias) (+residual)
@@ -221,6 +222,405 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Streaming variant for M <= 16 (every tree step): same math, different schedule.
+//   * balanced row partition: block b owns rows [b*R, b*R + R) with R = ceil(N / grid); tiles that
+//     stick out of the range are masked per lane (no load is issued for a masked row), so every
+//     block streams the same number of weight bytes whatever N is (11008 = 256 * 43);
+//   * software pipeline: the loads of K super-step j+1 (and j+2) are in flight while super-step j
+//     is multiplied, across tile-step boundaries and across the reduction barrier (raw s_barrier:
+//     it drains LDS traffic only, the weight loads stay outstanding);
+//   * the first weight loads are issued BEFORE the activation row indices are resolved (those are
+//     dependent global loads: ids -> row -> x);
+//   * weights are read once: non-temporal loads keep them from evicting x and the partial sums.
+// RT = 16-row weight tiles per tile-step (EPI_SILU_MUL: RT/2 gate tiles + RT/2 up tiles).
+// ---------------------------------------------------------------------------------------------
+template <int RT> struct SkStage { bf16x8 a[4][RT]; bf16x8 b[4]; };
+
+template <int RT, int EPI>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(SkinnyArgs p, int rows_per_block, int n_iter) {
+  constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;   // distinct 16-row groups per tile-step
+  constexpr int RPS = RTW * 16;                               // output rows per tile-step
+  __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][RT][64][4];
+  __shared__ float red_ss[2][SK_WAVES][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int row_lo = blockIdx.x * rows_per_block;
+  const int row_hi = min(p.N, row_lo + rows_per_block);
+  if (row_lo >= row_hi) return;
+  const int n_ts = (row_hi - row_lo + RPS - 1) / RPS;
+  // K % 128 == 0 (launcher): wave w owns K super-steps w, w+8, ...; waves may differ by one step
+  n_iter = ((p.K >> 7) - wave + SK_WAVES - 1) / SK_WAVES;
+  const int J = n_ts * n_iter;
+  const bool do_norm = p.norm_eps > 0.f;
+  const bf16_t* xa = p.x0;   // resolved after the first weight loads are in flight
+  const bf16_t* xb = p.x0;
+  const bool mvalid = r16 < p.M;
+
+  // No load below is predicated (a "load or zero" select makes hipcc branch around each load and
+  // wait vmcnt(0) behind it, which serialises the stream): rows outside [row_lo,row_hi) re-read the
+  // block's last valid row (same cache lines as the neighbouring lanes, so no extra HBM bytes) and
+  // token columns >= M re-read token 0; both only feed accumulator entries that are never stored.
+  auto load_w = [&](SkStage<RT>& st, int ts, int it) {
+    const int kb = (wave + SK_WAVES * it) << 7;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      int n = row_lo + ts * RPS + ((EPI == EPI_SILU_MUL) ? (t >> 1) : t) * 16 + r16;
+      n = n < row_hi ? n : row_hi - 1;
+      const bf16_t* base = (EPI == EPI_SILU_MUL && (t & 1)) ? p.W2 : p.W;
+      const bf16_t* wp = base + (int64_t)n * p.K + 8 * g + kb;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) st.a[s][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * 32));
+    }
+  };
+  auto load_x = [&](SkStage<RT>& st, int it) {
+    const int kb = (wave + SK_WAVES * it) << 7;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = kb + s * 32;
+      const bf16_t* src = (k < p.K0) ? xa : xb;
+      st.b[s] = *reinterpret_cast<const bf16x8*>(src + k);
+    }
+  };
+
+  f32x4 acc[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ssq = 0.f;
+  int parity = 0, done_ts = 0;
+
+  auto finish_tile_step = [&](int ts) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(&red[parity][wave][t][lane][0]) = acc[t];
+    if (do_norm) {
+      float v = ssq;
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) red_ss[parity][wave][r16] = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave == (done_ts & (SK_WAVES - 1))) {
+      float rstd = 1.f;
+      if (do_norm) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) v += red_ss[parity][w][r16];
+        rstd = rsqrtf(v / (float)p.K + p.norm_eps);
+      }
+      f32x4 sum[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) sv += *reinterpret_cast<const f32x4*>(&red[parity][w][t][lane][0]);
+        sum[t] = sv * rstd;
+      }
+      // D layout of mfma 16x16: col = lane&15 (token m), rows 4*(lane>>4)+r (features)
+      const int m = r16;
+      if (m < p.M) {
+#pragma unroll
+        for (int u = 0; u < RTW; ++u) {
+          const int nb = row_lo + ts * RPS + u * 16 + 4 * g;
+          float y[4];
+          if (EPI == EPI_SILU_MUL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float gt = rbf(sum[2 * u][r]), up = rbf(sum[2 * u + 1][r]);
+              y[r] = rbf(gt / (1.0f + __expf(-gt))) * up;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = nb + r;
+              float v = sum[u][r];
+              if (p.bias && n < row_hi) v += bf2f(p.bias[n]);
+              v = rbf(v);
+              if (p.res && n < row_hi) v = v + bf2f(p.res[(int64_t)m * p.ldr + n]);
+              y[r] = v;
+            }
+          }
+          bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
+          if (nb + 3 < row_hi && ((p.ldo | nb) & 3) == 0) {
+            uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+            *reinterpret_cast<uint2*>(o) = v;
+          } else {
+            for (int r = 0; r < 4; ++r) if (nb + r < row_hi) o[r] = f2bf(y[r]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ssq = 0.f;
+    parity ^= 1;
+    ++done_ts;
+  };
+
+  auto compute = [&](const SkStage<RT>& st, int ts, int it) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st.a[s][t], st.b[s], acc[t], 0, 0, 0);
+    if (do_norm) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float xv = (float)st.b[s][j]; ssq = fmaf(xv, xv, ssq); }
+    }
+    if (it == n_iter - 1) finish_tile_step(ts);
+  };
+
+  SkStage<RT> s0, s1;
+  int lts = 0, lit = 0;                       // load cursor
+  auto adv = [&](int& ts, int& it) { if (++it == n_iter) { it = 0; ++ts; } };
+  // prologue.  Gathered activations (fc: embed_tokens[flat_ids[tree_indices]]) need two dependent
+  // index loads before the first x load can be issued; the first two weight stages are requested
+  // before that chain so that HBM is already streaming (they are re-requested below, from L2, in
+  // the steady-state order: hipcc's vmcnt counting at the loop head follows the issue order of its
+  // predecessor blocks, and only an identical order keeps the refill of one stage in flight while
+  // the other stage is multiplied).
+  if (p.idx0 || p.idx1) {
+    load_w(s0, 0, 0);
+    { int t1 = 0, i1 = 0; adv(t1, i1); load_w(s1, t1, i1); }
+    int64_t ra = 0, rb = 0;
+    if (mvalid) {
+      const int m = r16;
+      if (p.ind0) ra = p.idx0[(int64_t)(m / p.ind_n) * p.idx0_bstride + p.ind0[m % p.ind_n]];
+      else ra = p.idx0 ? p.idx0[m] : m;
+      rb = p.idx1 ? p.idx1[m] : m;
+    }
+    xa = p.x0 + ra * p.ld0 + 8 * g;
+    xb = p.x1 ? (p.x1 + rb * p.ld1 + 8 * g - p.K0) : xa;
+  } else {
+    const int m = mvalid ? r16 : 0;
+    xa = p.x0 + (int64_t)m * p.ld0 + 8 * g;
+    xb = p.x1 ? (p.x1 + (int64_t)m * p.ld1 + 8 * g - p.K0) : xa;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_w(s0, lts, lit); load_x(s0, lit); adv(lts, lit);
+  __builtin_amdgcn_sched_barrier(0);
+  // unconditional (a stage past the end re-reads clamped rows): a guarded load here would make the
+  // loop head wait as if stage 1 had never been requested
+  load_w(s1, lts, lit); load_x(s1, lit); adv(lts, lit);
+  __builtin_amdgcn_sched_barrier(0);
+  int cts = 0, cit = 0;                       // compute cursor
+  // steady state: both stage refills are unconditional, so that hipcc can count vmcnt across the
+  // loop (a refill under `if` makes it wait for everything at the loop head)
+  int j = 0;
+  for (; j + 3 < J; j += 2) {
+    compute(s0, cts, cit); adv(cts, cit);
+    load_w(s0, lts, lit); load_x(s0, lit); adv(lts, lit);
+    compute(s1, cts, cit); adv(cts, cit);
+    load_w(s1, lts, lit); load_x(s1, lit); adv(lts, lit);
+  }
+  const int rem = J - j;                      // 1, 2 or 3 super-steps left; s0 = j, s1 = j + 1
+  compute(s0, cts, cit); adv(cts, cit);
+  if (rem >= 2) {
+    if (rem == 3) { load_w(s0, lts, lit); load_x(s0, lit); }
+    compute(s1, cts, cit); adv(cts, cit);
+    if (rem == 3) compute(s0, cts, cit);
+  }
+}
+
+
+// K == 128 * SK_WAVES * NI exactly (NI = 4: K = 4096, the q|k|v, o, gate/up and lm_head projections):
+// every wave owns NI fixed K super-steps, so its x fragments are loaded ONCE and stay in registers
+// for all of the block's rows (no per-tile-step re-read of x through L2: at 8 tokens that re-read
+// is half as many bytes again as the weight stream), the RMSNorm row statistics are computed once,
+// and the super-step loop is fully unrolled: stage parity, x fragment and refill target are static.
+template <int RT, int EPI, int NI>
+__global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
+  static_assert((NI & 1) == 0, "two register stages alternate");
+  constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;
+  constexpr int RPS = RTW * 16;
+  __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][RT][64][4];
+  __shared__ float red_ss[SK_WAVES][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int row_lo = blockIdx.x * rows_per_block;
+  const int row_hi = min(p.N, row_lo + rows_per_block);
+  if (row_lo >= row_hi) return;
+  const int n_ts = (row_hi - row_lo + RPS - 1) / RPS;
+  const bool do_norm = p.norm_eps > 0.f;
+  const bool mvalid = r16 < p.M;
+
+  bf16x8 a[2][4][RT];
+  auto load_w = [&](bf16x8 (&st)[4][RT], int ts, int it) {
+    const int kb = (wave + SK_WAVES * it) << 7;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      int n = row_lo + ts * RPS + ((EPI == EPI_SILU_MUL) ? (t >> 1) : t) * 16 + r16;
+      n = n < row_hi ? n : row_hi - 1;             // see gemm_skinny_stream_kernel: no predicated loads
+      const bf16_t* base = (EPI == EPI_SILU_MUL && (t & 1)) ? p.W2 : p.W;
+      const bf16_t* wp = base + (int64_t)n * p.K + 8 * g + kb;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) st[s][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * 32));
+    }
+  };
+  load_w(a[0], 0, 0);
+  load_w(a[1], 0, 1);
+  // activation rows (possibly gathered: two dependent index loads) -> registers, once
+  const bf16_t* xa;
+  const bf16_t* xb;
+  {
+    int64_t ra = 0, rb = 0;
+    if (mvalid) {
+      const int m = r16;
+      if (p.ind0) ra = p.idx0[(int64_t)(m / p.ind_n) * p.idx0_bstride + p.ind0[m % p.ind_n]];
+      else ra = p.idx0 ? p.idx0[m] : m;
+      rb = p.idx1 ? p.idx1[m] : m;
+    }
+    xa = p.x0 + ra * p.ld0 + 8 * g;
+    xb = p.x1 ? (p.x1 + rb * p.ld1 + 8 * g - p.K0) : xa;
+  }
+  bf16x8 xk[NI][4];
+#pragma unroll
+  for (int it = 0; it < NI; ++it)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = ((wave + SK_WAVES * it) << 7) + s * 32;
+      xk[it][s] = *reinterpret_cast<const bf16x8*>(((k < p.K0) ? xa : xb) + k);
+    }
+  float rstd = 1.f;
+  if (do_norm) {
+    float ssq = 0.f;
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float xv = (float)xk[it][s][j]; ssq = fmaf(xv, xv, ssq); }
+    ssq += __shfl_xor(ssq, 16, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (g == 0) red_ss[wave][r16] = ssq;
+    __syncthreads();
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < SK_WAVES; ++w) v += red_ss[w][r16];
+    rstd = rsqrtf(v / (float)p.K + p.norm_eps);
+  }
+
+  f32x4 acc[RT];
+  for (int ts = 0; ts < n_ts; ++ts) {
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it & 1][s][t], xk[it][s], acc[t], 0, 0, 0);
+      // refill this stage with the super-step two ahead (past the last tile-step: clamped rows)
+      load_w(a[it & 1], ts + (it + 2) / NI, (it + 2) % NI);
+    }
+    const int parity = ts & 1;
+#pragma unroll
+    for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(&red[parity][wave][t][lane][0]) = acc[t];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wave == (ts & (SK_WAVES - 1))) {
+      f32x4 sum[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < SK_WAVES; ++w) sv += *reinterpret_cast<const f32x4*>(&red[parity][w][t][lane][0]);
+        sum[t] = sv * rstd;
+      }
+      const int m = r16;
+      if (m < p.M) {
+#pragma unroll
+        for (int u = 0; u < RTW; ++u) {
+          const int nb = row_lo + ts * RPS + u * 16 + 4 * g;
+          float y[4];
+          if (EPI == EPI_SILU_MUL) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float gt = rbf(sum[2 * u][r]), up = rbf(sum[2 * u + 1][r]);
+              y[r] = rbf(gt / (1.0f + __expf(-gt))) * up;
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = nb + r;
+              float v = sum[u][r];
+              if (p.bias && n < row_hi) v += bf2f(p.bias[n]);
+              v = rbf(v);
+              if (p.res && n < row_hi) v = v + bf2f(p.res[(int64_t)m * p.ldr + n]);
+              y[r] = v;
+            }
+          }
+          bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
+          if (nb + 3 < row_hi && ((p.ldo | nb) & 3) == 0) {
+            uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+            *reinterpret_cast<uint2*>(o) = v;
+          } else {
+            for (int r = 0; r < 4; ++r) if (nb + r < row_hi) o[r] = f2bf(y[r]);
+          }
+        }
+      }
+    }
+  }
+}
+
+static int g_skinny_variant = -1;   // -1: read EAGLE_SKINNY_VARIANT once; 0: tile kernel, 1: streaming kernel
+static int g_sk_blocks_per_cu = 2;
+static int g_sk_min_rows = 16;
+extern "C" void eagle_debug_set_skinny_variant(int v, int blocks_per_cu, int min_rows) {
+  g_skinny_variant = v;
+  if (blocks_per_cu > 0) g_sk_blocks_per_cu = blocks_per_cu;
+  if (min_rows > 0) g_sk_min_rows = min_rows;
+}
+static int skinny_variant() {
+  if (g_skinny_variant < 0) {
+    const char* e = getenv("EAGLE_SKINNY_VARIANT");
+    g_skinny_variant = e ? atoi(e) : 3;
+  }
+  return g_skinny_variant;
+}
+static int sk_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int RT, int EPI>
+static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
+  int grid = sk_num_cus();                             // ~160 VGPRs: one 8-wave block per CU
+  int R = (a.N + grid - 1) / grid;
+  if (R < 16) R = 16;
+  R = (R + 3) & ~3;
+  grid = (a.N + R - 1) / R;
+  hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  return eagle_check_launch();
+}
+
+template <int RT, int EPI>
+static int launch_skinny_stream(const SkinnyArgs& a, hipStream_t st) {
+  constexpr int RPS = ((EPI == EPI_SILU_MUL) ? RT / 2 : RT) * 16;
+  static int occ = 0;                                  // resident 512-thread blocks per CU for this instantiation
+  if (!occ) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_skinny_stream_kernel<RT, EPI>, SK_WAVES * 64, 0) != hipSuccess || occ < 1) occ = 1;
+  }
+  int grid = sk_num_cus() * (occ < g_sk_blocks_per_cu ? occ : g_sk_blocks_per_cu);
+  int R = (a.N + grid - 1) / grid;
+  if (R < g_sk_min_rows) R = g_sk_min_rows;            // few rows per block waste MFMA lanes, not bandwidth
+  R = (R + 3) & ~3;                                    // keeps the 8-byte output stores aligned
+  grid = (a.N + R - 1) / R;
+  const int nfull = (a.K + 127) >> 7;
+  const int n_iter = (nfull + SK_WAVES - 1) / SK_WAVES;
+  (void)RPS;
+  hipLaunchKernelGGL((gemm_skinny_stream_kernel<RT, EPI>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R, n_iter);
+  return eagle_check_launch();
+}
+
 template <int RT, int MT, int EPI>
 static int launch_skinny(const SkinnyArgs& a, hipStream_t st) {
   const int rows_per_block = (EPI == EPI_SILU_MUL) ? 16 : RT * 16;
@@ -264,7 +664,17 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     a.out = (bf16_t*)out + (int64_t)m0 * ldo; a.ldo = ldo;
     a.M = mc; a.N = N; a.K = K;
     int rc;
-    if (epi == EPI_SILU_MUL) {
+    const int var = skinny_variant();   // 3 = per-shape choice (measured); 0/1/2 force one kernel family
+    const bool big = (epi == EPI_SILU_MUL) || N >= 8192;
+    if (mc <= 16 && K == 128 * SK_WAVES * 4 && (var == 2 || (var == 3 && big))) {
+      if (epi == EPI_SILU_MUL) rc = launch_skinny_keepx<2, EPI_SILU_MUL>(a, stream);
+      else if (N >= 8192) rc = launch_skinny_keepx<2, EPI_LINEAR>(a, stream);
+      else rc = launch_skinny_keepx<1, EPI_LINEAR>(a, stream);
+    } else if (mc <= 16 && (K & 127) == 0 && K >= 128 * SK_WAVES && (var == 1 || var == 2 || (var == 3 && K >= 8192))) {
+      if (epi == EPI_SILU_MUL) rc = launch_skinny_stream<2, EPI_SILU_MUL>(a, stream);
+      else if (N >= 8192) rc = launch_skinny_stream<2, EPI_LINEAR>(a, stream);
+      else rc = launch_skinny_stream<1, EPI_LINEAR>(a, stream);
+    } else if (epi == EPI_SILU_MUL) {
       if (mc <= 16) rc = launch_skinny<2, 1, EPI_SILU_MUL>(a, stream);
       else rc = launch_skinny<2, 2, EPI_SILU_MUL>(a, stream);
     } else if (mc <= 16) {

@@ -52,8 +52,10 @@ __device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) 
 
 // ---- stage 1, bf16: 32-bit keys ----
 __global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, int k,
-                                                                     int nwc, unsigned long long* __restrict__ cand) {
+                                                                     int nwc, unsigned long long* __restrict__ cand,
+                                                                     const int64_t* __restrict__ block_index, int64_t block_rows) {
   const int row = blockIdx.y;
+  if (block_index) x += *block_index * block_rows * ld;
   const int lane = threadIdx.x & 63;
   const int wc = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wc >= nwc) return;
@@ -107,8 +109,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16
 
 // ---- stage 1, fp32: 64-bit keys ----
 __global__ __launch_bounds__(TK_THREADS) void topk_stage1_f32_kernel(const float* __restrict__ x, int64_t ld, int V, int k,
-                                                                    int nwc, unsigned long long* __restrict__ cand) {
+                                                                    int nwc, unsigned long long* __restrict__ cand,
+                                                                    const int64_t* __restrict__ block_index, int64_t block_rows) {
   const int row = blockIdx.y;
+  if (block_index) x += *block_index * block_rows * ld;
   const int lane = threadIdx.x & 63;
   const int wc = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wc >= nwc) return;
@@ -141,8 +145,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_f32_kernel(const float
 template <typename T>
 __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
                                                                 const T* __restrict__ x, int64_t ld,
-                                                                int64_t* __restrict__ out_idx, T* __restrict__ out_val) {
+                                                                int64_t* __restrict__ out_idx, T* __restrict__ out_val,
+                                                                const int64_t* __restrict__ block_index, int64_t block_rows) {
   __shared__ unsigned long long surv[4 * TK_MAXK];
+  if (block_index) x += *block_index * block_rows * ld;
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   unsigned long long key[TK_CM];
 #pragma unroll
@@ -169,15 +175,17 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
   if (wave != 0) return;
   unsigned long long mine = 0;
   if (lane < 4 * k) mine = surv[(lane / k) * TK_MAXK + (lane % k)];
-  for (int r = 0; r < k; ++r) {
+  unsigned long long won = 0;                  // lane r keeps the r-th winner: the k value loads and
+  for (int r = 0; r < k; ++r) {                // stores below then go out together, not one per round
     const unsigned long long bm = wave_umax64(mine);
-    if (lane == 0) {
-      // fewer than k entries can only happen when V < k; emit index -1 then
-      const int64_t idx = bm ? (int64_t)(0xffffffffu - (uint32_t)(bm & 0xffffffffu)) : -1;
-      out_idx[(int64_t)row * k + r] = idx;
-      if (out_val) out_val[(int64_t)row * k + r] = idx >= 0 ? x[(int64_t)row * ld + idx] : (T)0;
-    }
+    if (lane == r) won = bm;
     if (bm != 0 && mine == bm) mine = 0;
+  }
+  if (lane < k) {
+    // fewer than k entries can only happen when V < k; emit index -1 then
+    const int64_t idx = won ? (int64_t)(0xffffffffu - (uint32_t)(won & 0xffffffffu)) : -1;
+    out_idx[(int64_t)row * k + lane] = idx;
+    if (out_val) out_val[(int64_t)row * k + lane] = idx >= 0 ? x[(int64_t)row * ld + idx] : (T)0;
   }
 }
 
@@ -188,21 +196,23 @@ extern "C" int64_t eagle_topk_workspace_bytes(int rows, int V, int k) {
 
 // dtype: 0 = bf16 logits, 1 = fp32 logits
 extern "C" int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V, int k,
-                                int64_t* out_idx, void* out_val, void* workspace, hipStream_t stream) {
+                                int64_t* out_idx, void* out_val, void* workspace, const int64_t* block_index,
+                                int64_t block_rows, hipStream_t stream) {
   if (!logits || !out_idx || !workspace) return EAGLE_ERR_ARG;
+  if (block_index && block_rows < rows) return EAGLE_ERR_SHAPE;
   if (rows < 1 || V < 1 || k < 1 || k > TK_MAXK || ld < V) return EAGLE_ERR_SHAPE;
   const int nwc = (V + TK_WCHUNK - 1) / TK_WCHUNK;
   if ((int64_t)nwc * k > TK_THREADS * TK_CM) return EAGLE_ERR_SHAPE;
   unsigned long long* cand = (unsigned long long*)workspace;
   dim3 g1((nwc + 3) / 4, rows);
   if (dtype == 0) {
-    hipLaunchKernelGGL(topk_stage1_bf16_kernel, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand);
+    hipLaunchKernelGGL(topk_stage1_bf16_kernel, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand, block_index, block_rows);
     hipLaunchKernelGGL(topk_stage2_kernel<bf16_t>, dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
-                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val);
+                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows);
   } else if (dtype == 1) {
-    hipLaunchKernelGGL(topk_stage1_f32_kernel, g1, dim3(TK_THREADS), 0, stream, (const float*)logits, ld, V, k, nwc, cand);
+    hipLaunchKernelGGL(topk_stage1_f32_kernel, g1, dim3(TK_THREADS), 0, stream, (const float*)logits, ld, V, k, nwc, cand, block_index, block_rows);
     hipLaunchKernelGGL(topk_stage2_kernel<float>, dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
-                       (const float*)logits, ld, out_idx, (float*)out_val);
+                       (const float*)logits, ld, out_idx, (float*)out_val, block_index, block_rows);
   } else {
     return EAGLE_ERR_ARG;
   }

@@ -41,9 +41,13 @@ __global__ __launch_bounds__(64) void greedy_accept_kernel(const int64_t* __rest
                                                           int32_t* __restrict__ accept_out, int64_t* __restrict__ result,
                                                           int64_t* __restrict__ next_ids_out, int32_t* __restrict__ n_acc_out,
                                                           int64_t* __restrict__ last_idx_out, int64_t* __restrict__ hid_idx0_out,
-                                                          int n0, int32_t* __restrict__ len_cur, int32_t* __restrict__ len_nxt) {
+                                                          int n0, int32_t* __restrict__ len_cur, int32_t* __restrict__ len_nxt,
+                                                          int64_t* __restrict__ cursor) {
   extern __shared__ int64_t tok[];  // [n_nodes]
   const int b = blockIdx.x, lane = threadIdx.x;
+  // ring cursor of the verifier's output buffers: kernels BEFORE this one in the chain (the argmax)
+  // read cursor[0], kernels AFTER it (the accepted-hidden gather) read cursor[1] = the same value
+  if (cursor && b == 0 && lane == 0) { const int64_t c = cursor[0]; cursor[1] = c; cursor[0] = c + 1; }
   const int64_t* fl = flat_ids + (int64_t)b * flat_bstride;
   const int64_t* tgt = target_argmax + (int64_t)b * n_nodes;
   for (int n = lane; n < n_nodes; n += 64) {
@@ -121,12 +125,12 @@ extern "C" int eagle_greedy_accept(const int64_t* root_token, const int64_t* fla
                                    const int64_t* target_argmax, const int32_t* prev_len, int64_t* tree_tok_out,
                                    int64_t* cart_out, int32_t* accept_out, int64_t* result, int64_t* next_ids_out,
                                    int32_t* n_acc_out, int64_t* last_idx_out, int64_t* hid_idx0_out, int n0,
-                                   int32_t* len_cur, int32_t* len_nxt, int B, hipStream_t stream) {
+                                   int32_t* len_cur, int32_t* len_nxt, int64_t* cursor, int B, hipStream_t stream) {
   if (!root_token || !flat_ids || !tree_indices || !retrieve || !target_argmax || !result) return EAGLE_ERR_ARG;
   if (n_nodes < 1 || n_nodes > 4096 || P < 1 || P >= (1 << 20) || W < 1 || B < 1) return EAGLE_ERR_SHAPE;
   hipLaunchKernelGGL(greedy_accept_kernel, dim3(B), dim3(64), (size_t)n_nodes * 8, stream, root_token, flat_ids,
                      flat_batch_stride, tree_indices, n_nodes, retrieve, P, W, target_argmax, prev_len, tree_tok_out,
-                     cart_out, accept_out, result, next_ids_out, n_acc_out, last_idx_out, hid_idx0_out, n0, len_cur, len_nxt);
+                     cart_out, accept_out, result, next_ids_out, n_acc_out, last_idx_out, hid_idx0_out, n0, len_cur, len_nxt, cursor);
   return eagle_check_launch();
 }
 
@@ -185,8 +189,10 @@ extern "C" int eagle_kv_compact_bf16(void* cache, int64_t n_slabs, int64_t slab_
 __global__ __launch_bounds__(256) void gather_accepted_kernel(const bf16_t* __restrict__ src, int n_nodes, int D,
                                                               const int64_t* __restrict__ retrieve, int W,
                                                               const int64_t* __restrict__ result, bf16_t* __restrict__ out,
-                                                              int64_t* __restrict__ root_io, int32_t* __restrict__ prev_len_io) {
+                                                              int64_t* __restrict__ root_io, int32_t* __restrict__ prev_len_io,
+                                                              const int64_t* __restrict__ src_block, int B) {
   const int b = blockIdx.y, j = blockIdx.x;
+  if (src_block) src += *src_block * (int64_t)B * n_nodes * D;
   if (j == 0 && threadIdx.x == 0) {  // verifier-side state for the next cycle
     if (root_io) root_io[b] = result[(int64_t)b * 4 + 2];
     if (prev_len_io) prev_len_io[b] = (int32_t)result[(int64_t)b * 4 + 3];
@@ -201,10 +207,10 @@ __global__ __launch_bounds__(256) void gather_accepted_kernel(const bf16_t* __re
 
 extern "C" int eagle_gather_accepted_bf16(const void* src, int n_nodes, int D, const int64_t* retrieve, int W,
                                           const int64_t* result, void* out, int64_t* root_io, int32_t* prev_len_io,
-                                          int B, hipStream_t stream) {
+                                          const int64_t* src_block, int B, hipStream_t stream) {
   if (!src || !retrieve || !result || !out) return EAGLE_ERR_ARG;
   if (n_nodes < 1 || D < 8 || (D & 7) || W < 1 || B < 1) return EAGLE_ERR_SHAPE;
   hipLaunchKernelGGL(gather_accepted_kernel, dim3(W, B), dim3(256), 0, stream, (const bf16_t*)src, n_nodes, D, retrieve, W,
-                     result, (bf16_t*)out, root_io, prev_len_io);
+                     result, (bf16_t*)out, root_io, prev_len_io, src_block, B);
   return eagle_check_launch();
 }

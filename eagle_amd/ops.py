@@ -268,8 +268,11 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 
 def topk(logits: torch.Tensor, k: int, want_values: bool = True,
          out_idx: Optional[torch.Tensor] = None, out_val: Optional[torch.Tensor] = None,
-         workspace: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
-    """(values, indices) of the k largest per row: value desc, index asc.  logits [rows, V]."""
+         workspace: Optional[torch.Tensor] = None, block_index: Optional[torch.Tensor] = None,
+         rows: Optional[int] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+    """(values, indices) of the k largest per row: value desc, index asc.  logits [rows, V].
+    block_index (device int64 scalar) + rows: logits is a ring [blocks*rows, V] and block
+    ``block_index[0]`` is read (cursor in device memory: graph-capturable)."""
     if logits.dtype == BF16:
         dt = 0
     elif logits.dtype == torch.float32:
@@ -278,7 +281,11 @@ def topk(logits: torch.Tensor, k: int, want_values: bool = True,
         raise TypeError("topk: bf16 or fp32 logits")
     if not logits.is_cuda:
         raise _hip.HipKernelError("topk: device tensor required")
-    rows, V = logits.shape
+    total_rows, V = logits.shape
+    if block_index is None:
+        rows = total_rows
+    elif rows is None or total_rows % rows:
+        raise ValueError("topk: ring reads need rows per block dividing the ring")
     if logits.stride(1) != 1:
         raise ValueError("topk: logits rows must be contiguous")
     if out_idx is None:
@@ -288,7 +295,7 @@ def topk(logits: torch.Tensor, k: int, want_values: bool = True,
     nb = query("eagle_topk_workspace_bytes", rows, V, k)
     ws = workspace if workspace is not None else _workspace(nb, logits.device)
     call("eagle_topk_vocab", ptr(logits), logits.stride(0), dt, rows, V, k, ptr(out_idx),
-         ptr(out_val) if want_values else None, ptr(ws), stream())
+         ptr(out_val) if want_values else None, ptr(ws), ptr(block_index), rows, stream())
     return (out_val if want_values else None), out_idx
 
 
@@ -315,7 +322,8 @@ def greedy_accept(root_token: torch.Tensor, flat_ids: torch.Tensor, tree_indices
                   B: int = 1, want_debug: bool = False, next_ids: Optional[torch.Tensor] = None,
                   n_acc: Optional[torch.Tensor] = None, result: Optional[torch.Tensor] = None,
                   last_idx: Optional[torch.Tensor] = None, hid_idx0: Optional[torch.Tensor] = None,
-                  len_cur: Optional[torch.Tensor] = None, len_nxt: Optional[torch.Tensor] = None):
+                  len_cur: Optional[torch.Tensor] = None, len_nxt: Optional[torch.Tensor] = None,
+                  cursor: Optional[torch.Tensor] = None):
     """result [B,4] int64 = {best_path, accept_length, next_token, new_len}."""
     n_nodes = tree_indices.numel()
     P_, W = retrieve.shape
@@ -331,7 +339,7 @@ def greedy_accept(root_token: torch.Tensor, flat_ids: torch.Tensor, tree_indices
     call("eagle_greedy_accept", ptr(root_token), ptr(flat), flat.stride(0), ptr(tree_indices), n_nodes,
          ptr(retrieve), P_, W, ptr(target_argmax), ptr(prev_len), ptr(tok), ptr(cart), ptr(acc), ptr(result), ptr(next_ids), ptr(n_acc),
          ptr(last_idx), ptr(hid_idx0), (hid_idx0.numel() // B if hid_idx0 is not None else 0), ptr(len_cur), ptr(len_nxt),
-         B, stream())
+         ptr(cursor), B, stream())
     return (result, tok, cart, acc) if want_debug else result
 
 
@@ -349,14 +357,14 @@ def kv_compact(cache: torch.Tensor, B: int, inner: int, retrieve: torch.Tensor, 
 
 def gather_accepted(src: torch.Tensor, retrieve: torch.Tensor, result: torch.Tensor, B: int = 1,
                     root_io: Optional[torch.Tensor] = None, prev_len_io: Optional[torch.Tensor] = None,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, src_block: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(src, "src")
     n_nodes, D = src.shape[-2], src.shape[-1]
     W = retrieve.shape[1]
     if out is None:
         out = torch.empty((B, W, D), dtype=BF16, device=src.device)
     call("eagle_gather_accepted_bf16", ptr(src), n_nodes, D, ptr(retrieve), W, ptr(result), ptr(out), ptr(root_io),
-         ptr(prev_len_io), B, stream())
+         ptr(prev_len_io), ptr(src_block), B, stream())
     return out
 
 

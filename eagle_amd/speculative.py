@@ -75,6 +75,7 @@ class EagleDrafter:
         self.last_idx = torch.zeros(B, dtype=torch.int64, device=dev)          # last valid catch-up row
         self.hid_idx0 = torch.zeros(B * self.n0, dtype=torch.int64, device=dev)  # ... repeated per depth-1 node
         self.acc_hidden = torch.zeros((B, self.W, self.D), dtype=BF16, device=dev)
+        self._tgt = None                                                         # verifier argmax per tree node
 
     @property
     def stable_len(self) -> torch.Tensor:
@@ -154,29 +155,40 @@ class EagleDrafter:
             prev_row0 = s.row_base
 
     # -------------------------------------------------------------- verify side
-    def verify(self, root_token: torch.Tensor, target_logits: torch.Tensor, prev_len: torch.Tensor):
+    def verify(self, root_token: torch.Tensor, target_logits: torch.Tensor, prev_len: torch.Tensor,
+               cursor: Optional[torch.Tensor] = None):
         """target_logits [B, n_nodes, V] (bf16 or fp32): the verifier's logits at every tree node;
         root_token [B] int64; prev_len [B] int32 = verifier cache rows before the tree.
         Fills and returns result [B,4] = {best_path, accept_length, next_token, new_len}; also
-        fills next_ids [B,W] and n_acc [B] (inputs of the next ``draft``)."""
+        fills next_ids [B,W] and n_acc [B] (inputs of the next ``draft``).
+        cursor [2] (device int64): target_logits is then a RING [slots, B, n_nodes, V] of verifier
+        output buffers and slot cursor[0] is read; the chain advances the cursor on the device
+        (cursor[1] keeps the slot for ``compact``), so a captured cycle needs no host update."""
         B, n = self.B, self.tb.n_nodes
-        tgt = ops.topk(target_logits.reshape(B * n, -1), 1, want_values=False, workspace=self._ws)[1].view(B, n)
-        return ops.greedy_accept(root_token, self.flat_ids, self.tb.tree_indices, self.tb.retrieve_indices, tgt,
+        if self._tgt is None:
+            self._tgt = torch.empty((B, n), dtype=torch.int64, device=self.dev)
+        V = target_logits.shape[-1]
+        ops.topk(target_logits.reshape(-1, V), 1, want_values=False, workspace=self._ws, out_idx=self._tgt.view(B * n, 1),
+                 block_index=None if cursor is None else cursor[0:1], rows=B * n)
+        return ops.greedy_accept(root_token, self.flat_ids, self.tb.tree_indices, self.tb.retrieve_indices, self._tgt,
                                  prev_len, B=B, next_ids=self.next_ids, n_acc=self.n_acc, result=self.result,
                                  last_idx=self.last_idx, hid_idx0=self.hid_idx0, len_cur=self.len_cur,
-                                 len_nxt=self.len_nxt)
+                                 len_nxt=self.len_nxt, cursor=cursor)
 
     def compact(self, prev_len: torch.Tensor, target_kv: Optional[torch.Tensor], target_hidden: torch.Tensor,
-                kv_inner: int = 1, root_io: Optional[torch.Tensor] = None, update_prev_len: bool = False) -> torch.Tensor:
+                kv_inner: int = 1, root_io: Optional[torch.Tensor] = None, update_prev_len: bool = False,
+                cursor: Optional[torch.Tensor] = None) -> torch.Tensor:
         """In-place compaction of the verifier's KV cache ([outer, B, inner, cap, hd], the tree's rows
         at [prev_len, prev_len+n_nodes)) and gather of the accepted path's hidden states
         [B, W, D] (zeros beyond accept_length+1; a persistent buffer) for the next ``draft``.
         root_io / update_prev_len: also overwrite the caller's root-token and prev_len arrays with
         next_token / new_len, so a serving loop needs no host round trip between cycles."""
+        # (with ``cursor``, target_hidden is the ring [slots, B, n_nodes, D] matching ``verify``'s)
         if target_kv is not None:
             ops.kv_compact(target_kv, self.B, kv_inner, self.tb.retrieve_indices, self.result, prev_len, self.model._err)
         return ops.gather_accepted(target_hidden, self.tb.retrieve_indices, self.result, B=self.B, root_io=root_io,
-                                   prev_len_io=prev_len if update_prev_len else None, out=self.acc_hidden)
+                                   prev_len_io=prev_len if update_prev_len else None, out=self.acc_hidden,
+                                   src_block=None if cursor is None else cursor[1:2])
 
     def check_errors(self):
         """Host-side look at the device error flag (sync point; not for the hot loop)."""

@@ -122,10 +122,14 @@ int eagle_rope_qk_bf16(void* qkv, int64_t ld, const int64_t* position_ids, const
  * [rows,k] int64, out_val [rows,k] (logits dtype, may be NULL), k <= 16.
  * workspace: eagle_topk_workspace_bytes(rows, V, k).
  * Replaces torch.topk(last_headout, top_k) of the expansion loop (top_k = 10, eagle/llama2.py:11;
- * SURVEY.md a20) and, with k = 1, torch.max(..., 2) index selection (eagle/train.py:115-116). */
+ * SURVEY.md a20) and, with k = 1, torch.max(..., 2) index selection (eagle/train.py:115-116).
+ * block_index (device int64, may be NULL) / block_rows: the rows read are
+ * [*block_index * block_rows, + rows) of `logits` -- a ring of verifier output buffers whose cursor
+ * lives in device memory, so that a captured graph needs no host-side pointer update. */
 int64_t eagle_topk_workspace_bytes(int rows, int V, int k);
 int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V, int k,
-                     int64_t* out_idx, void* out_val, void* workspace, eagle_stream_t stream);
+                     int64_t* out_idx, void* out_val, void* workspace, const int64_t* block_index,
+                     int64_t block_rows, eagle_stream_t stream);
 
 /* Static-tree kernels (Llama2Model.init_tree / tree_mask hooks,
  * eagle/llama2.py:453-458 -- the algorithm itself is the upstream EAGLE-1 one). */
@@ -139,13 +143,15 @@ int eagle_tree_gather_ids(const int64_t* flat_ids, int64_t flat_batch_stride, co
  * accept_length + 1: the inputs of the next draft cycle; optional draft-side state for that cycle:
  * last_idx_out [B] = b*W + accept_length (last valid catch-up row), hid_idx0_out [B,n0] = the same
  * row repeated for the n0 depth-1 nodes, and the in/out length pair len_cur/len_nxt [B] int32
- * (len_cur = len_nxt; len_nxt += accept_length + 1). */
+ * (len_cur = len_nxt; len_nxt += accept_length + 1); optional cursor [2] (device int64): ring cursor
+ * of the verifier's output buffers, cursor[1] = cursor[0]; cursor[0] += 1 (the argmax before this
+ * kernel reads cursor[0], the gather after it reads cursor[1]). */
 int eagle_greedy_accept(const int64_t* root_token, const int64_t* flat_ids, int64_t flat_batch_stride,
                         const int64_t* tree_indices, int n_nodes, const int64_t* retrieve, int P, int W,
                         const int64_t* target_argmax, const int32_t* prev_len, int64_t* tree_tok_out,
                         int64_t* cart_out, int32_t* accept_out, int64_t* result, int64_t* next_ids_out,
                         int32_t* n_acc_out, int64_t* last_idx_out, int64_t* hid_idx0_out, int n0,
-                        int32_t* len_cur, int32_t* len_nxt, int B, eagle_stream_t stream);
+                        int32_t* len_cur, int32_t* len_nxt, int64_t* cursor, int B, eagle_stream_t stream);
 /* In-place compaction of the accepted path's KV rows: cache viewed as [n_slabs][cap][row_elems]
  * with slab = (outer*B + b)*inner + i; rows prev_len[b] + retrieve[best][j] -> prev_len[b] + j. */
 int eagle_kv_compact_bf16(void* cache, int64_t n_slabs, int64_t slab_stride, int row_elems, int B,
@@ -153,10 +159,11 @@ int eagle_kv_compact_bf16(void* cache, int64_t n_slabs, int64_t slab_stride, int
                           const int32_t* prev_len, int cap, int* err_flag, eagle_stream_t stream);
 /* out[b][j] = src[b][retrieve[best_b][j]] for j <= accept_length_b (zeros after).  Optional
  * root_io [B] / prev_len_io [B]: overwritten with next_token / new_len for the next cycle (this is
- * the last kernel of the verify chain, so earlier kernels still saw the old values). */
+ * the last kernel of the verify chain, so earlier kernels still saw the old values).  Optional
+ * src_block (device int64): src is a ring of [B, n_nodes, D] buffers and block *src_block is read. */
 int eagle_gather_accepted_bf16(const void* src, int n_nodes, int D, const int64_t* retrieve, int W,
                                const int64_t* result, void* out, int64_t* root_io, int32_t* prev_len_io,
-                               int B, eagle_stream_t stream);
+                               const int64_t* src_block, int B, eagle_stream_t stream);
 
 /* Fused soft-label CE + smooth-L1 + agreement at the logits level.
  * Replaces eagle/train.py:108-123 (== eagle/train_tp.py:90-105).
