@@ -16,6 +16,7 @@
 // output columns of one row (8-byte bf16 / 16-byte fp32 stores).  Workgroup ids are remapped so
 // that consecutive ids on one XCD walk down M within a fixed N panel (L2 reuse of the B panel).
 #include "common.h"
+#include <stdlib.h>
 
 #define GM_BM 128
 #define GM_BN 128
@@ -150,6 +151,19 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(GemmArgs p) {
 
 static inline bool gm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// gemm_mfma8.hip: 256x256 tiles, DMA in flight across barriers
+int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                          const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, hipStream_t stream);
+static int g_gemm8_mode = -1;   // 0: never, 1: whenever legal, 2: by shape (default); EAGLE_GEMM8 overrides
+extern "C" void eagle_debug_set_gemm8(int mode) { g_gemm8_mode = mode; }
+static bool use_gemm8(int M, int N, int K) {
+  if (g_gemm8_mode < 0) { const char* e = getenv("EAGLE_GEMM8"); g_gemm8_mode = e ? atoi(e) : 2; }
+  if (g_gemm8_mode == 0 || K < 2 * GM_BK) return false;
+  if (g_gemm8_mode == 1) return true;
+  const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  return t256 >= 512;            // at least two full rounds of 256x256 tiles over the 256 CUs
+}
+
 // See include/eagle_hip.h for the contract.
 extern "C" int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                   const void* bias, const void* res, int64_t ldr, int M, int N, int K,
@@ -158,6 +172,8 @@ extern "C" int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   if (M < 1 || N < 1 || K < GM_BK || (K % GM_BK)) return EAGLE_ERR_SHAPE;
   if ((lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N || (res && ldr < N)) return EAGLE_ERR_SHAPE;
   if (!gm_al16(A) || !gm_al16(B) || !gm_al16(C)) return EAGLE_ERR_SHAPE;
+  if (use_gemm8(M, N, K))
+    return eagle_launch_gemm_nt8(A, lda, B, ldb, C, ldc, bias, res, ldr, M, N, K, out_f32, accumulate, stream);
   GemmArgs a;
   a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;

@@ -1,0 +1,208 @@
+// 256x256x64 bf16 "NT" GEMM for the big training GEMMs (lm_head forward on target and predict,
+// gate|up, their wgrad shapes): 8 waves, LDS-DMA staging kept in flight ACROSS barriers.
+//
+//   C[M,N] = epilogue( A[M,K] . B[N,K]^T )      same contract as gemm_nt_kernel (gemm_mfma.hip)
+//
+// Why a second kernel: the 128x128 kernel drains its LDS-DMA (vmcnt(0)) at one barrier per K step
+// and tops out near 0.9 PFLOP/s whatever is tuned around it.  Here every K tile is cut into four
+// phases; each phase issues ONE 16 KB half-tile of a later K tile, multiplies one quadrant of the
+// wave's 128x64 output (16 MFMAs) and ends in a raw s_barrier that waits for LDS traffic only.  The
+// DMA is retired once per K tile by a counted vmcnt that leaves the two youngest half-tiles in
+// flight, so HBM/L2 latency is hidden behind four phases of MFMA work instead of being exposed at
+// a barrier.
+//
+// Wave (wr, wc), wr in {0,1}, wc in {0..3}: rows wr*128.., columns wc*64.. of the 256x256 tile, so
+// a wave reads A half-tile `wr` and B half-tile `wc>>1` only.  Phases of K tile t (buffer b = t&1):
+//   P1  read A(mh=0) 8x b128 + B(nh=0) 4x   stage A0(t+1) -> buffer b^1     MFMA quadrant (0,0)
+//   P2  read B(nh=1) 4x                      stage A1(t+1) -> buffer b^1     MFMA quadrant (0,1)
+//   P3  read A(mh=1) 8x                      stage B0(t+2) -> buffer b       MFMA quadrant (1,1)
+//   P4  (B(nh=0) is still in registers)      stage B1(t+2) -> buffer b       MFMA quadrant (1,0)
+//       s_waitcnt vmcnt(4): everything but the P3/P4 half-tiles has landed = all of tile t+1
+// WAR: a B half of buffer b is last read in P2, an A half in P3; each is restaged one barrier later
+// at the earliest.  RAW: tile t+1 is complete at P4's wait (per thread), published by P4's barrier,
+// first read in P1 of t+1.  Staging past the last K tile re-reads the last tile (never consumed):
+// the loop body stays branch-free so the vmcnt arithmetic holds.
+// LDS image of a half-tile: [128 rows][8 x 16 B], 16-byte chunk XOR (row & 7) -- applied on the
+// per-lane SOURCE address of the DMA (its LDS destination is lane-linear) and on the ds_read side.
+#include "common.h"
+
+#define G8_BM 256
+#define G8_BN 256
+#define G8_BK 64
+#define G8_THREADS 512
+#define G8_HALF (128 * G8_BK)           // elements per half-tile (16 KB)
+
+struct Gemm8Args {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const bf16_t* bias;
+  const bf16_t* res; int64_t ldr;
+  int M, N, K;
+  int out_f32, accumulate;
+  int tiles_m, tiles_n;
+};
+
+// half-tile `h` (0/1) of operand X (rows r0.., clamped to nrows-1) at K tile kt -> lds
+__device__ __forceinline__ void g8_stage(const bf16_t* X, int64_t ld, int nrows, int r0, int h, int kt, bf16_t* lds, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int L = i * G8_THREADS + tid;        // 16-byte slot in the [128][8] image
+    const int row = L >> 3, slot = L & 7;
+    const int chunk = slot ^ (row & 7);
+    int gr = r0 + h * 128 + row;
+    gr = gr < nrows ? gr : nrows - 1;
+    const bf16_t* g = X + (int64_t)gr * ld + kt * G8_BK + chunk * 8;
+    bf16_t* d = lds + (i * G8_THREADS + wave * 64) * 8;   // wave-uniform base; HW adds lane*16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
+  // ONE shared array (a second LDS object makes hipcc drain the DMA before every ds_read):
+  // [buffer 2][A0, A1, B0, B1][128 x 64]  = 128 KB
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * 4 * G8_HALF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int orig = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int tn = wgid / p.tiles_m, tm = wgid - tn * p.tiles_m;
+  const int m0 = tm * G8_BM, n0 = tn * G8_BN;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / G8_BK;
+  auto kt_of = [&](int t) { return t < nk ? t : nk - 1; };
+  auto hbuf = [&](int buf, int which) { return lds + (buf * 4 + which) * G8_HALF; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
+  auto stage_a = [&](int h, int t) { g8_stage(p.A, p.lda, p.M, m0, h, kt_of(t), hbuf(t & 1, h), tid); };
+  auto stage_b = [&](int h, int t) { g8_stage(p.B, p.ldb, p.N, n0, h, kt_of(t), hbuf(t & 1, 2 + h), tid); };
+
+  // prologue: tile 0 complete, B halves of tile 1 in flight
+  stage_b(0, 0); stage_b(1, 0); stage_a(0, 0); stage_a(1, 0);
+  stage_b(0, 1); stage_b(1, 1);
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  bf16x8 af[4][2], bf0[2][2], bf1[2][2];     // A: 4 m-tiles x 2 k-steps; B quadrant nh: 2 n-tiles x 2 k-steps
+  const int a_row0 = r16;                                  // + mh*64 + i*16 within the wave's A half
+  const int b_row0 = (wc & 1) * 64 + r16;                  // + nh*32 + j*16 within the wave's B half
+  auto read_a = [&](const bf16_t* la, int mh) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = a_row0 + mh * 64 + i * 16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        af[i][s] = *reinterpret_cast<const bf16x8*>(la + row * G8_BK + (((4 * s + g) ^ (row & 7)) << 3));
+    }
+  };
+  auto read_b = [&](const bf16_t* lb, int nh, bf16x8 (&bf)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = b_row0 + nh * 32 + j * 16;
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        bf[j][s] = *reinterpret_cast<const bf16x8*>(lb + row * G8_BK + (((4 * s + g) ^ (row & 7)) << 3));
+    }
+  };
+
+#define G8_MFMA(MH, NH, BF)                                                                           \
+  __builtin_amdgcn_s_setprio(1);                                                                      \
+  _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                       \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
+    acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][s], af[i][s], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+
+  for (int t = 0; t < nk; ++t) {
+    const bf16_t* la = hbuf(t & 1, wr);
+    const bf16_t* lb = hbuf(t & 1, 2 + (wc >> 1));
+    // P1
+    read_b(lb, 0, bf0);
+    read_a(la, 0);
+    stage_a(0, t + 1);
+    G8_MFMA(0, 0, bf0)
+    __builtin_amdgcn_s_barrier();
+    // P2
+    read_b(lb, 1, bf1);
+    stage_a(1, t + 1);
+    G8_MFMA(0, 1, bf1)
+    __builtin_amdgcn_s_barrier();
+    // P3
+    read_a(la, 1);
+    stage_b(0, t + 2);
+    G8_MFMA(1, 1, bf1)
+    __builtin_amdgcn_s_barrier();
+    // P4
+    stage_b(1, t + 2);
+    G8_MFMA(1, 0, bf0)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the never-consumed tail stages must land before the LDS is released
+#undef G8_MFMA
+
+  // epilogue: acc[i][j][r] = C[m0 + wr*128 + i*16 + r16][n0 + wc*64 + j*16 + 4g + r]
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wr * 128 + i * 16 + r16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = n0 + wc * 64 + j * 16 + 4 * g;
+      if (nb >= p.N) continue;
+      float y[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int n = nb + rr;
+        float v = acc[i][j][rr];
+        if (p.bias && n < p.N) v += bf2f(p.bias[n]);
+        if (p.res && n < p.N) v = rbf(v) + bf2f(p.res[(int64_t)m * p.ldr + n]);
+        y[rr] = v;
+      }
+      const bool full = (nb + 3 < p.N) && ((p.ldc & 3) == 0);
+      if (p.out_f32) {
+        float* o = (float*)p.C + (int64_t)m * p.ldc + nb;
+        if (full) {
+          float4 v = make_float4(y[0], y[1], y[2], y[3]);
+          if (p.accumulate) { const float4 old = *reinterpret_cast<const float4*>(o); v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+          *reinterpret_cast<float4*>(o) = v;
+        } else {
+          for (int rr = 0; rr < 4; ++rr) if (nb + rr < p.N) o[rr] = p.accumulate ? o[rr] + y[rr] : y[rr];
+        }
+      } else {
+        bf16_t* o = (bf16_t*)p.C + (int64_t)m * p.ldc + nb;
+        if (full) {
+          if (p.accumulate) {
+            const uint2 old = *reinterpret_cast<const uint2*>(o);
+            y[0] += lo_bf(old.x); y[1] += hi_bf(old.x); y[2] += lo_bf(old.y); y[3] += hi_bf(old.y);
+          }
+          *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+        } else {
+          for (int rr = 0; rr < 4; ++rr) if (nb + rr < p.N) o[rr] = f2bf(p.accumulate ? bf2f(o[rr]) + y[rr] : y[rr]);
+        }
+      }
+    }
+  }
+}
+
+// Called by eagle_gemm_nt_bf16 (gemm_mfma.hip) after its argument checks.
+int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                          const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, hipStream_t stream) {
+  Gemm8Args a;
+  a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
+  a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
+  a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = (N + G8_BN - 1) / G8_BN;
+  hipLaunchKernelGGL(gemm_nt8_kernel, dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
+  return eagle_check_launch();
+}

@@ -478,6 +478,43 @@ def test_gemm_nt(M, N, K):
     close(ya, acc + ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="gemm_nt accumulate fp32")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 4096), (300, 515, 192), (2048, 1024, 512), (1, 9, 128), (257, 255, 64 * 7)])
+def test_gemm_nt_256_tile_kernel(M, N, K):
+    """The 256x256 kernel (DMA in flight across barriers) forced on every shape, against fp32 torch
+    and bit-for-bit-close to the 128x128 kernel's contract: ragged M/N, bias, residual, fp32, accumulate."""
+    import ctypes
+    from eagle_amd import _hip, ops
+    setm = _hip.lib().eagle_debug_set_gemm8
+    setm.argtypes, setm.restype = [ctypes.c_int], None
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(BF)
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    ref = A.float() @ Bm.float().t()
+    bias = torch.randn(N, generator=g).to(BF)
+    res = torch.randn(M, N, generator=g).to(BF)
+    acc = torch.randn(M, N, generator=g)
+    try:
+        setm(1)
+        for _ in range(3):   # repeated launches: a staging race would show as run-to-run differences
+            y = ops.gemm_nt(A.to(dev()), Bm.to(dev()))
+            close(y, ref, what="gemm8 bf16")
+        y_again = ops.gemm_nt(A.to(dev()), Bm.to(dev()))
+        assert torch.equal(y, y_again)
+        close(ops.gemm_nt(A.to(dev()), Bm.to(dev()), out_dtype=torch.float32), ref, rtol=2e-3,
+              atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="gemm8 fp32")
+        close(ops.gemm_nt(A.to(dev()), Bm.to(dev()), bias=bias.to(dev()), res=res.to(dev())),
+              (ref + bias.float()).to(BF).float() + res.float(), what="gemm8 bias+res")
+        ya = ops.gemm_nt(A.to(dev()), Bm.to(dev()), out=acc.to(dev()).clone(), accumulate=True)
+        close(ya, acc + ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="gemm8 accumulate")
+        setm(0)
+        y128 = ops.gemm_nt(A.to(dev()), Bm.to(dev()), out_dtype=torch.float32)
+        setm(1)
+        y256 = ops.gemm_nt(A.to(dev()), Bm.to(dev()), out_dtype=torch.float32)
+        assert torch.equal(y128, y256)        # same K order and MFMA shape: identical fp32 sums
+    finally:
+        setm(2)
+
+
 def test_transpose():
     from eagle_amd import ops
     g = torch.Generator().manual_seed(4)
@@ -538,3 +575,52 @@ def test_rope_qk_forward_and_inverse():
     lhs = (Ra * bvec.float()[:, : 2 * H * hd]).sum()
     rhs = (a.float()[:, : 2 * H * hd] * Rtb).sum()
     assert abs(float(lhs - rhs)) <= 2e-2 * abs(float(lhs)) + 1.0
+
+
+def test_verify_ring_cursor_matches_direct_buffers():
+    """verify/compact reading slot cursor[0] of a ring of verifier outputs (cursor advanced on the
+    device) must give what the same calls give on the slot's tensors passed directly."""
+    from eagle_amd.config import DraftConfig
+    from eagle_amd.llama2 import Llama2Model
+    from eagle_amd.speculative import EagleDrafter
+    d = dev()
+    dims = dm.DraftDims(hidden=256, inter=512, heads=2, kv_heads=2, vocab=1000)
+    w = dm.init_weights(dims, seed=1, std=0.08)
+    cfg = DraftConfig(hidden_size=256, intermediate_size=512, num_attention_heads=2, vocab_size=1000)
+    model = Llama2Model(cfg)
+    model.load_state_dict(w)
+    model = model.to(BF).to(d).eval()
+    g = torch.Generator().manual_seed(3)
+    ctx, S = 12, 3
+    hidden = torch.randn(1, ctx, 256, generator=g).to(BF).to(d)
+    tokens = torch.randint(0, 1000, (1, ctx + 1), generator=g).to(d)
+    lm_head = (torch.randn(1000, 256, generator=g) * 0.3).to(BF).to(d)
+    tb = ot.generate_tree_buffers()
+    ring_l = (torch.randn(S, 1, tb.n_nodes, 1000, generator=g) * 2).to(BF).to(d)
+    ring_h = torch.randn(S, 1, tb.n_nodes, 256, generator=g).to(BF).to(d)
+    with torch.no_grad():
+        runs = []
+        for use_ring in (False, True):
+            dr = EagleDrafter(model, lm_head, batch=1, max_ctx=128)
+            flat, _ = dr.prefill(hidden, tokens)
+            for s in range(S):   # make every slot accept something different
+                tok = torch.cat([tokens[:, -1], flat[0].reshape(-1)])[dr.tb.tree_indices]
+                ring_l[s, 0, 0, int(tok[1 + s])] = 50.0
+            root = tokens[:, -1].clone()
+            prev = torch.tensor([ctx], dtype=torch.int32, device=d)
+            cursor = torch.zeros(2, dtype=torch.int64, device=d)
+            log = []
+            for s in range(S):
+                if use_ring:
+                    res = dr.verify(root, ring_l, prev, cursor=cursor).clone()
+                    acc = dr.compact(prev, None, ring_h, root_io=root, update_prev_len=True, cursor=cursor).clone()
+                else:
+                    res = dr.verify(root, ring_l[s], prev).clone()
+                    acc = dr.compact(prev, None, ring_h[s], root_io=root, update_prev_len=True).clone()
+                dr.draft(acc, dr.next_ids)
+                log.append((res.cpu(), acc.cpu(), dr.flat_ids.clone().cpu()))
+            if use_ring:
+                assert cursor.tolist() == [S, S - 1]
+            runs.append(log)
+    for a, b in zip(*runs):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
