@@ -31,6 +31,8 @@ P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, I, L, F, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
     "eagle_gemm_nt_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, P]),
+    "eagle_gemm_nt_splitk_workspace_bytes": (L, [I, I, I]),
+    "eagle_gemm_nt_splitk_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, P, P]),
     "eagle_transpose_bf16": (I, [P, L, P, L, I, I, I, P]),
     "eagle_rmsnorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),
     "eagle_rmsnorm_bwd_workspace_bytes": (L, [I, I]),

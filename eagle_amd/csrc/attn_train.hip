@@ -14,6 +14,7 @@
 // 16*(j>>2) + 4g + (j&3)); the other operand of that product is an LDS tile stored transposed
 // with the same slot order.
 #include "common.h"
+#include <stdlib.h>
 
 #define AT_THREADS 256
 #define AT_HD 128
@@ -74,6 +75,7 @@ struct AttnTrainArgs {
   int B, L, H;
   float scale2;                        // log2(e)/sqrt(hd)
   float scale;                         // 1/sqrt(hd)
+  int dbg;                             // timing experiments only (EAGLE_ATTN_DBG): wrong results when non-zero
 };
 
 // ------------------------------------------------------------------ forward
@@ -161,6 +163,213 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd_kernel(AttnTrainArg
       *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) = w;
     }
     if (g == 0) p.lse[((int64_t)b * p.H + h) * L + qi] = m + log2f(lsum);
+  }
+}
+
+// Workgroup -> (pair index, head, batch) for the second-generation kernels: a 1-D grid whose ids
+// b, b+8, ... share an XCD (round-robin dispatch) is remapped so that every XCD owns a CONTIGUOUS
+// range of (batch, head) groups: the workgroups that re-read one head's K/V (or Q/dO) tiles then
+// hit the same 4 MB L2 instead of pulling the head through all eight (speed only, never correctness).
+__device__ __forceinline__ void a2_work(int npairs, int H, int& pair, int& h, int& b) {
+  const int n = gridDim.x, id = blockIdx.x;
+  int w = id;
+  if ((n & 7) == 0) w = (id & 7) * (n >> 3) + (id >> 3);
+  pair = w % npairs;
+  const int bh = w / npairs;
+  h = bh % H;
+  b = bh / H;
+}
+
+// ------------------------------------------------------------------ forward, second generation
+// 128 queries per workgroup (32 per wave = two 16-query MFMA column groups), 64-key tiles, K and V
+// staged ROW-MAJOR in LDS ([64][128] bf16, 256-byte rows, 16-byte chunks XOR-swizzled so that both
+// the row reads and the transposing reads are (nearly) conflict-free); V^T fragments come straight
+// from the row-major image through ds_read_b64_tr_b16, two reads per 32-key step: the lane-local
+// k order of the P fragment (two stacked 16-key score tiles: slot (g,j) <-> key 16*(j>>2)+4g+(j&3))
+// is exactly two 4-row blocks per 16-lane group.  Global loads of tile t+1 are issued before tile t
+// is multiplied and written to the other LDS buffer after it: one barrier per tile.
+#define A2_QB 128
+#define A2_KB 64
+typedef __attribute__((ext_vector_type(4))) short a2_s4;
+__device__ __forceinline__ int a2_off(int row, int ch) {   // byte offset of 16-byte chunk ch of a tile row
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <bool PAIR>
+__global__ __launch_bounds__(AT_THREADS) void attn_train_fwd2_kernel(AttnTrainArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][A2_KB * 256];   // [buffer][K|V] 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+  const int D = p.H * AT_HD, L = p.L;
+  // causal balance: a workgroup takes query block i AND block nqb-1-i (their key counts add up to
+  // the same total for every i), heavy one first
+  const int nqb = (L + A2_QB - 1) / A2_QB;
+  int bx, h, b;
+  a2_work(PAIR ? (nqb + 1) / 2 : nqb, p.H, bx, h, b);
+  const bf16_t* base = p.qkv + (int64_t)b * L * p.ld + h * AT_HD;
+  const bf16_t* kbase = base + D;
+  const bf16_t* vbase = base + 2 * D;
+  for (int pass = 0; pass < (PAIR ? 2 : 1); ++pass) {
+  const int qb = pass == 0 ? nqb - 1 - bx : bx;
+  if (pass == 1 && qb >= nqb - 1 - bx) break;
+  const int qw = qb * A2_QB + wave * 32;          // first query of this wave
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    const int qi = min(qw + 16 * qg + r16, L - 1);   // rows past L re-read the last row; never stored
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[qg][s] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qi * p.ld + 32 * s + 8 * g);
+  }
+  f32x4 o[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { o[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[i][1] = o[i][0]; }
+  float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+  const int kend = min(L, qb * A2_QB + A2_QB);   // causal: keys below the end of this query block
+  const int nt = (kend + A2_KB - 1) / A2_KB;
+
+  // K/V tiles go HBM/L2 -> LDS by LDS-DMA (no staging registers, no ds_write): a wave-instruction
+  // fills 1 KB = 4 rows x 256 B lane-linearly, so the chunk swizzle of a2_off() is applied to the
+  // per-lane SOURCE address (lane l: row l>>4, slot l&15 holds chunk slot ^ f(row)).  Never
+  // predicated: keys past L re-read the last key row and are masked out of the scores.
+  auto stage = [&](int k0, int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = i * AT_THREADS + tid;                 // 16-byte slot of the [64][16] tile image
+      const int trow = c >> 4, slot = c & 15;
+      const int ch = slot ^ (((trow & 3) << 2) | ((trow >> 2) & 3));
+      const int row = min(k0 + trow, L - 1);
+      const bf16_t* gk = kbase + (int64_t)row * p.ld + ch * 8;
+      const bf16_t* gv = vbase + (int64_t)row * p.ld + ch * 8;
+      char* dk = &lds[buf][0][(i * AT_THREADS + wave * 64) * 16];   // wave-uniform base; HW adds lane*16
+      char* dv = &lds[buf][1][(i * AT_THREADS + wave * 64) * 16];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gk,
+                                       (__attribute__((address_space(3))) void*)dk, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv,
+                                       (__attribute__((address_space(3))) void*)dv, 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  // transposing-read lane geometry: lane i = 4q+p of a 16-lane group addresses row q, columns 4p..4p+3
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  for (int t = 0; t < nt; ++t) {
+    const int k0 = t * A2_KB;
+    if (!(p.dbg & 1)) stage(k0 + A2_KB, (t + 1) & 1);   // unconditional (past the end: clamped rows, never read)
+    const char* Kt = &lds[t & 1][0][0];
+    const char* Vt = &lds[t & 1][1][0];
+    if (k0 <= qw + 31 && !(p.dbg & 8)) {         // wave-uniform: at least one visible key in this tile
+      f32x4 sc[4][2];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) { sc[kt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[kt][1] = sc[kt][0]; }
+      // all 16 K fragments are requested before the first MFMA (one wave per SIMD: nothing else
+      // hides the LDS latency); d-step outermost: 8 independent accumulators between two MFMAs on
+      // the same one
+      bf16x8 kfr[4][4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) kfr[s][kt] = *reinterpret_cast<const bf16x8*>(Kt + a2_off(16 * kt + r16, 4 * s + g));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+          sc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[s][kt], qf[0][s], sc[kt][0], 0, 0, 0);
+          sc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[s][kt], qf[1][s], sc[kt][1], 0, 0, 0);
+        }
+      // the V^T fragments of this tile are requested now, ahead of the softmax arithmetic
+      bf16x8 vfr[2][8];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const int r0 = 32 * ks + 4 * g + tq;
+          const a2_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) a2_s4*)(Vt + a2_off(r0, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
+          const a2_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) a2_s4*)(Vt + a2_off(r0 + 16, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
+          union { struct { a2_s4 a, b; } s; bf16x8 v; } u;
+          u.s.a = lo; u.s.b = hi;
+          vfr[ks][dt] = u.v;
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      const bool need_mask = (k0 + A2_KB - 1 > qw) || (k0 + A2_KB > L);   // wave-uniform
+      bf16x8 pf[2][2];
+      if (p.dbg & 2) { pf[0][0] = pack_frag(sc[0][0], sc[1][0]); pf[0][1] = pack_frag(sc[2][0], sc[3][0]); pf[1][0] = pack_frag(sc[0][1], sc[1][1]); pf[1][1] = pack_frag(sc[2][1], sc[3][1]); }
+      else
+#pragma unroll
+      for (int qg = 0; qg < 2; ++qg) {
+        // VALU diet (this loop, not the MFMAs, bounds the kernel): the running maximum is kept on the
+        // RAW scores (the scale is positive), each probability is one fma + one v_exp, masking only
+        // runs on tiles that touch the diagonal or the end of the sequence, and the 64-register
+        // rescale of O is skipped when no lane's maximum moved.  Key 0 is visible to every query,
+        // so after the first tile every maximum is finite: no -inf guards.
+        if (need_mask) {
+          const int qi = qw + 16 * qg + r16;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = k0 + 16 * kt + 4 * g + r;
+              sc[kt][qg][r] = (key <= qi && key < L) ? sc[kt][qg][r] : -INFINITY;
+            }
+        }
+        float mx = m[qg];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+          mx = fmaxf(fmaxf(mx, fmaxf(sc[kt][qg][0], sc[kt][qg][1])), fmaxf(sc[kt][qg][2], sc[kt][qg][3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float neg = -mx * p.scale2;
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(sc[kt][qg][r], p.scale2, neg));
+            sc[kt][qg][r] = e;
+            ps += e;
+          }
+        if (__builtin_amdgcn_ballot_w64(mx != m[qg])) {         // wave-uniform: some row's maximum moved
+          const float alpha = __builtin_amdgcn_exp2f(fmaf(m[qg], p.scale2, neg));   // m = -inf (first tile) -> 0
+          lsum[qg] *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt) o[dt][qg] *= alpha;
+          m[qg] = mx;
+        }
+        lsum[qg] += ps;
+        pf[qg][0] = pack_frag(sc[0][qg], sc[1][qg]);
+        pf[qg][1] = pack_frag(sc[2][qg], sc[3][qg]);
+      }
+      if (!(p.dbg & 4))
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[ks][dt], pf[0][ks], o[dt][0], 0, 0, 0);
+          o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[ks][dt], pf[1][ks], o[dt][1], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile landed (this thread's share) ...
+    __builtin_amdgcn_s_barrier();                                   // ... and everybody's; this tile's reads are done
+  }
+#pragma unroll
+  for (int qg = 0; qg < 2; ++qg) {
+    float ls = lsum[qg];
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    const int qi = qw + 16 * qg + r16;
+    if (qi < L) {
+      const float inv = ls > 0.f ? 1.f / ls : 0.f;
+      bf16_t* orow = p.out + ((int64_t)b * L + qi) * p.ldo + h * AT_HD;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) {
+        const uint2 w = make_uint2(pack2bf(o[dt][qg][0] * inv, o[dt][qg][1] * inv), pack2bf(o[dt][qg][2] * inv, o[dt][qg][3] * inv));
+        *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) = w;
+      }
+      if (g == 0) p.lse[((int64_t)b * p.H + h) * L + qi] = m[qg] * p.scale2 + log2f(ls);
+    }
+  }
   }
 }
 
@@ -348,6 +557,295 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_dkv_kernel(AttnTrainArg
   }
 }
 
+// ------------------------------------------------------------------ backward, second generation
+// Same building blocks as attn_train_fwd2_kernel: [64][128] bf16 tiles staged by LDS-DMA with the
+// a2_off() chunk swizzle on the source address, one image serving the row reads (ds_read_b128) and
+// the transposing reads (ds_read_b64_tr_b16), every fragment of a tile requested before the MFMAs
+// that use it, no predicated loads (rows past L re-read row L-1 and are masked out of P), a
+// workgroup takes block i and block n-1-i of the causal triangle.
+__device__ __forceinline__ void a2_stage_tile(const bf16_t* gbase, int64_t ld, int row0, int nrows, char* dst, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * AT_THREADS + tid;
+    const int trow = c >> 4, slot = c & 15;
+    const int ch = slot ^ (((trow & 3) << 2) | ((trow >> 2) & 3));
+    const int row = min(row0 + trow, nrows - 1);
+    const bf16_t* g = gbase + (int64_t)row * ld + ch * 8;
+    char* d = dst + (i * AT_THREADS + wave * 64) * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+  }
+}
+__device__ __forceinline__ bf16x8 a2_row_frag(const char* tile, int row, int ch) {
+  return *reinterpret_cast<const bf16x8*>(tile + a2_off(row, ch));
+}
+// transposed fragment for k-step ks (32 tile rows) and 16-column block dt: element j of lane group g
+// = tile[32*ks + 16*(j>>2) + 4g + (j&3)][16*dt + (lane&15)]
+__device__ __forceinline__ bf16x8 a2_tr_frag(const char* tile, int ks, int dt, int g, int tq, int tp) {
+  const int r0 = 32 * ks + 4 * g + tq;
+  const a2_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) a2_s4*)(tile + a2_off(r0, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
+  const a2_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) a2_s4*)(tile + a2_off(r0 + 16, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
+  union { struct { a2_s4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+// dQ (query stationary): 128 queries per pass (32 per wave), 64-key tiles of K and V.
+__global__ __launch_bounds__(AT_THREADS) void attn_train_dq2_kernel(AttnTrainArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][A2_KB * 256];   // [buffer][K|V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  const int D = p.H * AT_HD, L = p.L;
+  const int nqb = (L + A2_QB - 1) / A2_QB;
+  int bx, h, b;
+  a2_work((nqb + 1) / 2, p.H, bx, h, b);
+  const bf16_t* base = p.qkv + (int64_t)b * L * p.ld + h * AT_HD;
+  const bf16_t* kbase = base + D;
+  const bf16_t* vbase = base + 2 * D;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int qb = pass == 0 ? nqb - 1 - bx : bx;
+    if (pass == 1 && qb >= nqb - 1 - bx) break;
+    const int qw = qb * A2_QB + wave * 32;
+    bf16x8 qf[2][4], dof[2][4];
+    float nlse[2], dl[2];
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const int qi = min(qw + 16 * qg + r16, L - 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qf[qg][s] = *reinterpret_cast<const bf16x8*>(base + (int64_t)qi * p.ld + 32 * s + 8 * g);
+        dof[qg][s] = *reinterpret_cast<const bf16x8*>(p.dout + ((int64_t)b * L + qi) * p.lddo + h * AT_HD + 32 * s + 8 * g);
+      }
+      nlse[qg] = -p.lse[((int64_t)b * p.H + h) * L + qi];
+      dl[qg] = p.delta[((int64_t)b * p.H + h) * L + qi];
+    }
+    f32x4 dq[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dq[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dq[i][1] = dq[i][0]; }
+    const int kend = min(L, qb * A2_QB + A2_QB);
+    const int nt = (kend + A2_KB - 1) / A2_KB;
+    a2_stage_tile(kbase, p.ld, 0, L, &lds[0][0][0], tid);
+    a2_stage_tile(vbase, p.ld, 0, L, &lds[0][1][0], tid);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nt; ++t) {
+      const int k0 = t * A2_KB;
+      a2_stage_tile(kbase, p.ld, k0 + A2_KB, L, &lds[(t + 1) & 1][0][0], tid);
+      a2_stage_tile(vbase, p.ld, k0 + A2_KB, L, &lds[(t + 1) & 1][1][0], tid);
+      const char* Kt = &lds[t & 1][0][0];
+      const char* Vt = &lds[t & 1][1][0];
+      if (k0 <= qw + 31) {
+        f32x4 sc[4][2], dp[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { sc[kt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[kt][1] = sc[kt][0]; dp[kt][0] = sc[kt][0]; dp[kt][1] = sc[kt][0]; }
+        bf16x8 kfr[4][4], vrr[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            kfr[s][kt] = a2_row_frag(Kt, 16 * kt + r16, 4 * s + g);
+            vrr[s][kt] = a2_row_frag(Vt, 16 * kt + r16, 4 * s + g);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt) {
+            sc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[s][kt], qf[0][s], sc[kt][0], 0, 0, 0);
+            sc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[s][kt], qf[1][s], sc[kt][1], 0, 0, 0);
+            dp[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vrr[s][kt], dof[0][s], dp[kt][0], 0, 0, 0);
+            dp[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vrr[s][kt], dof[1][s], dp[kt][1], 0, 0, 0);
+          }
+        bf16x8 ktf[2][8];                       // K^T fragments: requested ahead of the exp arithmetic
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt) ktf[ks][dt] = a2_tr_frag(Kt, ks, dt, g, tq, tp);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool need_mask = (k0 + A2_KB - 1 > qw) || (k0 + A2_KB > L);
+        bf16x8 dsf[2][2];
+#pragma unroll
+        for (int qg = 0; qg < 2; ++qg) {
+          const int qi = qw + 16 * qg + r16;
+#pragma unroll
+          for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float pr = __builtin_amdgcn_exp2f(fmaf(sc[kt][qg][r], p.scale2, nlse[qg]));
+              if (need_mask) { const int key = k0 + 16 * kt + 4 * g + r; pr = (key <= qi && key < L) ? pr : 0.f; }
+              sc[kt][qg][r] = pr * (dp[kt][qg][r] - dl[qg]);
+            }
+          dsf[qg][0] = pack_frag(sc[0][qg], sc[1][qg]);
+          dsf[qg][1] = pack_frag(sc[2][qg], sc[3][qg]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt) {
+            dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[ks][dt], dsf[0][ks], dq[dt][0], 0, 0, 0);
+            dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[ks][dt], dsf[1][ks], dq[dt][1], 0, 0, 0);
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int qg = 0; qg < 2; ++qg) {
+      const int qi = qw + 16 * qg + r16;
+      if (qi < L) {
+        bf16_t* drow = p.dqkv + ((int64_t)b * L + qi) * p.lddq + h * AT_HD;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          const uint2 w = make_uint2(pack2bf(dq[dt][qg][0] * p.scale, dq[dt][qg][1] * p.scale),
+                                     pack2bf(dq[dt][qg][2] * p.scale, dq[dt][qg][3] * p.scale));
+          *reinterpret_cast<uint2*>(drow + dt * 16 + 4 * g) = w;
+        }
+      }
+    }
+  }
+}
+
+// dK, dV (key stationary): 128 keys per pass (32 per wave), 64-query tiles of Q and dO; the rows'
+// -lse and delta ride along in the same LDS array (two 4-byte LDS-DMA pieces per tile).
+#define A2_TILE_BYTES (A2_KB * 256)
+#define A2_BUF_BYTES (2 * A2_TILE_BYTES + 2 * A2_KB * 4)
+__global__ __launch_bounds__(AT_THREADS) void attn_train_dkv2_kernel(AttnTrainArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * A2_BUF_BYTES];   // [buffer]{Q tile, dO tile, lse[64], delta[64]}
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+  const int D = p.H * AT_HD, L = p.L;
+  int bx, h, b;
+  a2_work(((L + A2_QB - 1) / A2_QB + 1) / 2, p.H, bx, h, b);
+  const bf16_t* base = p.qkv + (int64_t)b * L * p.ld + h * AT_HD;
+  const bf16_t* dobase = p.dout + (int64_t)b * L * p.lddo + h * AT_HD;
+  const float* lse_g = p.lse + ((int64_t)b * p.H + h) * L;
+  const float* dl_g = p.delta + ((int64_t)b * p.H + h) * L;
+  const int nkb = (L + A2_QB - 1) / A2_QB;
+  auto stage = [&](int q0, int buf) {
+    char* bb = lds + buf * A2_BUF_BYTES;
+    a2_stage_tile(base, p.ld, q0, L, bb, tid);
+    a2_stage_tile(dobase, p.lddo, q0, L, bb + A2_TILE_BYTES, tid);
+    if (wave < 2) {   // wave-uniform: one 4-byte piece per lane, lane-linear destination
+      const float* src = (wave == 0 ? lse_g : dl_g) + min(q0 + lane, L - 1);
+      char* d = bb + 2 * A2_TILE_BYTES + wave * (A2_KB * 4);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)d, 4, 0, 0);
+    }
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    const int kb_ = pass == 0 ? bx : nkb - 1 - bx;    // key block 0 is the heaviest
+    if (pass == 1 && kb_ <= bx) break;
+    const int kw = kb_ * A2_QB + wave * 32;        // first key of this wave
+    bf16x8 kf[2][4], vf[2][4];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int ki = min(kw + 16 * kg + r16, L - 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kf[kg][s] = *reinterpret_cast<const bf16x8*>(base + D + (int64_t)ki * p.ld + 32 * s + 8 * g);
+        vf[kg][s] = *reinterpret_cast<const bf16x8*>(base + 2 * D + (int64_t)ki * p.ld + 32 * s + 8 * g);
+      }
+    }
+    f32x4 dk[8][2], dv[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dk[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dk[i][1] = dk[i][0]; dv[i][0] = dk[i][0]; dv[i][1] = dk[i][0]; }
+    const int t0 = (kb_ * A2_QB) / A2_KB;          // causal: query tiles from the one holding the block's first key
+    const int nt = (L + A2_KB - 1) / A2_KB;
+    stage(t0 * A2_KB, t0 & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = t0; t < nt; ++t) {
+      const int q0 = t * A2_KB;
+      stage(q0 + A2_KB, (t + 1) & 1);
+      const char* Qt = lds + (t & 1) * A2_BUF_BYTES;
+      const char* Ot = Qt + A2_TILE_BYTES;
+      const float* lse_s = reinterpret_cast<const float*>(Qt + 2 * A2_TILE_BYTES);
+      const float* dl_s = lse_s + A2_KB;
+      if (q0 + A2_KB - 1 >= kw) {                  // wave-uniform: some query of the tile sees this wave's keys
+        f32x4 sc[4][2], dp[4][2];
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) { sc[qt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[qt][1] = sc[qt][0]; dp[qt][0] = sc[qt][0]; dp[qt][1] = sc[qt][0]; }
+        bf16x8 qrr[4][4], orr[4][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int qt = 0; qt < 4; ++qt) {
+            qrr[s][qt] = a2_row_frag(Qt, 16 * qt + r16, 4 * s + g);
+            orr[s][qt] = a2_row_frag(Ot, 16 * qt + r16, 4 * s + g);
+          }
+        f32x4 lser[4], dlr[4];                     // this lane's rows 4g..4g+3 of each 16-query tile
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+          lser[qt] = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
+          dlr[qt] = *reinterpret_cast<const f32x4*>(dl_s + 16 * qt + 4 * g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int qt = 0; qt < 4; ++qt) {
+            sc[qt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrr[s][qt], kf[0][s], sc[qt][0], 0, 0, 0);   // S[q][key]: rows = queries
+            sc[qt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrr[s][qt], kf[1][s], sc[qt][1], 0, 0, 0);
+            dp[qt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orr[s][qt], vf[0][s], dp[qt][0], 0, 0, 0);   // dP = dO . V^T
+            dp[qt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orr[s][qt], vf[1][s], dp[qt][1], 0, 0, 0);
+          }
+        bf16x8 otf[2][8], qtf[2][8];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt) { otf[ks][dt] = a2_tr_frag(Ot, ks, dt, g, tq, tp); qtf[ks][dt] = a2_tr_frag(Qt, ks, dt, g, tq, tp); }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool need_mask = (q0 < kw + 31) || (q0 + A2_KB > L);   // tile touches the diagonal / the end
+        bf16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+          const int ki = kw + 16 * kg + r16;
+          f32x4 pr[4], dsv[4];
+#pragma unroll
+          for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float e = __builtin_amdgcn_exp2f(fmaf(sc[qt][kg][r], p.scale2, -lser[qt][r]));
+              if (need_mask) { const int qi = q0 + 16 * qt + 4 * g + r; e = (ki <= qi && qi < L && ki < L) ? e : 0.f; }
+              pr[qt][r] = e;
+              dsv[qt][r] = e * (dp[qt][kg][r] - dlr[qt][r]);
+            }
+          pf[kg][0] = pack_frag(pr[0], pr[1]);   pf[kg][1] = pack_frag(pr[2], pr[3]);
+          dsf[kg][0] = pack_frag(dsv[0], dsv[1]); dsf[kg][1] = pack_frag(dsv[2], dsv[3]);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int dt = 0; dt < 8; ++dt) {
+            dv[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf[ks][dt], pf[0][ks], dv[dt][0], 0, 0, 0);
+            dv[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf[ks][dt], pf[1][ks], dv[dt][1], 0, 0, 0);
+            dk[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[ks][dt], dsf[0][ks], dk[dt][0], 0, 0, 0);
+            dk[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[ks][dt], dsf[1][ks], dk[dt][1], 0, 0, 0);
+          }
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int ki = kw + 16 * kg + r16;
+      if (ki < L) {
+        bf16_t* drow = p.dqkv + ((int64_t)b * L + ki) * p.lddq + h * AT_HD;
+#pragma unroll
+        for (int dt = 0; dt < 8; ++dt) {
+          *reinterpret_cast<uint2*>(drow + D + dt * 16 + 4 * g) =
+              make_uint2(pack2bf(dk[dt][kg][0] * p.scale, dk[dt][kg][1] * p.scale), pack2bf(dk[dt][kg][2] * p.scale, dk[dt][kg][3] * p.scale));
+          *reinterpret_cast<uint2*>(drow + 2 * D + dt * 16 + 4 * g) =
+              make_uint2(pack2bf(dv[dt][kg][0], dv[dt][kg][1]), pack2bf(dv[dt][kg][2], dv[dt][kg][3]));
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ RoPE over the q and k sections, in place
 // forward: x' = bf16(bf16(x*cos) + bf16(rot(x)*sin)) (eagle/llama2.py:56-69); inverse != 0 applies
 // the transposed rotation (x*cos - rot(x)*sin): the backward of the forward pass.
@@ -397,6 +895,7 @@ extern "C" int eagle_rope_qk_bf16(void* qkv, int64_t ld, const int64_t* position
   return eagle_check_launch();
 }
 
+static int g_attn_dbg = 0;
 extern "C" int eagle_attn_train_fwd_bf16(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int L, int H,
                                          int hd, hipStream_t stream) {
   int rc = at_check(qkv, ld, B, L, H, hd);
@@ -405,7 +904,12 @@ extern "C" int eagle_attn_train_fwd_bf16(const void* qkv, int64_t ld, void* out,
   AttnTrainArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = ld; a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse;
   a.B = B; a.L = L; a.H = H; a.scale = 1.0f / sqrtf((float)hd); a.scale2 = a.scale * LOG2E;
-  hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((L + AT_QB - 1) / AT_QB, H, B), dim3(AT_THREADS), 0, stream, a);
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("EAGLE_ATTN_FWD"); v = e ? atoi(e) : 2; const char* d = getenv("EAGLE_ATTN_DBG"); g_attn_dbg = d ? atoi(d) : 0; }
+  a.dbg = g_attn_dbg;
+  if (v == 2) hipLaunchKernelGGL(attn_train_fwd2_kernel<true>, dim3(((L + A2_QB - 1) / A2_QB + 1) / 2 * H * B), dim3(AT_THREADS), 0, stream, a);
+  else if (v == 3) hipLaunchKernelGGL(attn_train_fwd2_kernel<false>, dim3((L + A2_QB - 1) / A2_QB * H * B), dim3(AT_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((L + AT_QB - 1) / AT_QB, H, B), dim3(AT_THREADS), 0, stream, a);
   return eagle_check_launch();
 }
 
@@ -425,6 +929,16 @@ extern "C" int eagle_attn_train_bwd_bf16(const void* qkv, int64_t ld, const void
   a.qkv = (const bf16_t*)qkv; a.ld = ld; a.lse = (float*)lse; a.dout = (const bf16_t*)dout; a.lddo = lddo; a.delta = delta_ws;
   a.dqkv = (bf16_t*)dqkv; a.lddq = lddq; a.B = B; a.L = L; a.H = H;
   a.scale = 1.0f / sqrtf((float)hd); a.scale2 = a.scale * LOG2E;
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("EAGLE_ATTN_BWD"); v = e ? atoi(e) : 2; }
+  if (v == 2) {
+    const dim3 grid2(((L + A2_QB - 1) / A2_QB + 1) / 2 * H * B);
+    hipLaunchKernelGGL(attn_train_dq2_kernel, grid2, dim3(AT_THREADS), 0, stream, a);
+    rc = eagle_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_train_dkv2_kernel, grid2, dim3(AT_THREADS), 0, stream, a);
+    return eagle_check_launch();
+  }
   const dim3 grid((L + AT_QB - 1) / AT_QB, H, B);
   hipLaunchKernelGGL(attn_train_dq_kernel, grid, dim3(AT_THREADS), 0, stream, a);
   rc = eagle_check_launch();

@@ -153,7 +153,8 @@ static inline bool gm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(
 
 // gemm_mfma8.hip: 256x256 tiles, DMA in flight across barriers
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
-                          const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, hipStream_t stream);
+                          const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
+                          void* workspace, hipStream_t stream);
 static int g_gemm8_mode = -1;   // 0: never, 1: whenever legal, 2: by shape (default); EAGLE_GEMM8 overrides
 extern "C" void eagle_debug_set_gemm8(int mode) { g_gemm8_mode = mode; }
 static bool use_gemm8(int M, int N, int K) {
@@ -173,7 +174,7 @@ extern "C" int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   if ((lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N || (res && ldr < N)) return EAGLE_ERR_SHAPE;
   if (!gm_al16(A) || !gm_al16(B) || !gm_al16(C)) return EAGLE_ERR_SHAPE;
   if (use_gemm8(M, N, K))
-    return eagle_launch_gemm_nt8(A, lda, B, ldb, C, ldc, bias, res, ldr, M, N, K, out_f32, accumulate, stream);
+    return eagle_launch_gemm_nt8(A, lda, B, ldb, C, ldc, bias, res, ldr, M, N, K, out_f32, accumulate, 1, nullptr, stream);
   GemmArgs a;
   a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
@@ -181,6 +182,24 @@ extern "C" int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   a.tiles_m = (M + GM_BM - 1) / GM_BM; a.tiles_n = (N + GM_BN - 1) / GM_BN;
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(a.tiles_m * a.tiles_n), dim3(GM_THREADS), 0, stream, a);
   return eagle_check_launch();
+}
+
+// Split-K form for few output tiles and a very long K (the lm_head dgrad: M = tokens, N = D, K = V):
+// ksplit slices of K run as separate workgroups of the 256x256 kernel into fp32 partials
+// [ksplit][M][N] in `workspace` (eagle_gemm_nt_splitk_workspace_bytes), a second launch sums them
+// and applies the epilogue.  ksplit <= 1 is eagle_gemm_nt_bf16.
+extern "C" int64_t eagle_gemm_nt_splitk_workspace_bytes(int M, int N, int ksplit) {
+  return ksplit > 1 ? (int64_t)ksplit * M * N * 4 : 0;
+}
+extern "C" int eagle_gemm_nt_splitk_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                                         const void* bias, const void* res, int64_t ldr, int M, int N, int K, int out_f32,
+                                         int accumulate, int ksplit, void* workspace, hipStream_t stream) {
+  if (ksplit <= 1) return eagle_gemm_nt_bf16(A, lda, B, ldb, C, ldc, bias, res, ldr, M, N, K, out_f32, accumulate, stream);
+  if (!A || !B || !C || !workspace) return EAGLE_ERR_ARG;
+  if (M < 1 || N < 1 || K < 2 * GM_BK || (K % GM_BK)) return EAGLE_ERR_SHAPE;
+  if ((lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N || (res && ldr < N)) return EAGLE_ERR_SHAPE;
+  if (!gm_al16(A) || !gm_al16(B) || !gm_al16(C) || !gm_al16(workspace)) return EAGLE_ERR_SHAPE;
+  return eagle_launch_gemm_nt8(A, lda, B, ldb, C, ldc, bias, res, ldr, M, N, K, out_f32, accumulate, ksplit, workspace, stream);
 }
 
 // out[C, R_pad] = in[R, C]^T (bf16), 64x64 tiles through LDS; columns [R, R_pad) are zero-filled so

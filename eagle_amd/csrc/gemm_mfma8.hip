@@ -41,6 +41,9 @@ struct Gemm8Args {
   int M, N, K;
   int out_f32, accumulate;
   int tiles_m, tiles_n;
+  int ksplit;          // > 1: grid = tiles x ksplit, slice s multiplies K tiles [s*kchunk, ...) into partial[s]
+  int kchunk;          // K tiles per slice
+  float* partial;      // [ksplit][M][N] fp32 (split-K only)
 };
 
 // half-tile `h` (0/1) of operand X (rows r0.., clamped to nrows-1) at K tile kt -> lds
@@ -68,10 +71,13 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   const int r16 = lane & 15, g = lane >> 4;
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int nwg = p.tiles_m * p.tiles_n;
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int nwg = ntile * p.ksplit;
   const int orig = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int wgid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  const int kslice = wgid0 / ntile;                 // slices of one tile sit ntile ids apart
+  const int wgid = wgid0 - kslice * ntile;
   const int tn = wgid / p.tiles_m, tm = wgid - tn * p.tiles_m;
   const int m0 = tm * G8_BM, n0 = tn * G8_BN;
 
@@ -81,8 +87,10 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / G8_BK;
-  auto kt_of = [&](int t) { return t < nk ? t : nk - 1; };
+  const int nk_all = p.K / G8_BK;
+  const int kt0 = kslice * p.kchunk;
+  const int nk = min(p.kchunk, nk_all - kt0);       // K tiles of this slice (>= 1: launcher)
+  auto kt_of = [&](int t) { return kt0 + (t < nk ? t : nk - 1); };
   auto hbuf = [&](int buf, int which) { return lds + (buf * 4 + which) * G8_HALF; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
   auto stage_a = [&](int h, int t) { g8_stage(p.A, p.lda, p.M, m0, h, kt_of(t), hbuf(t & 1, h), tid); };
   auto stage_b = [&](int h, int t) { g8_stage(p.B, p.ldb, p.N, n0, h, kt_of(t), hbuf(t & 1, 2 + h), tid); };
@@ -152,6 +160,22 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
 #undef G8_MFMA
 
   // epilogue: acc[i][j][r] = C[m0 + wr*128 + i*16 + r16][n0 + wc*64 + j*16 + 4g + r]
+  if (p.ksplit > 1) {                               // split-K: raw fp32 partial sums; gemm8_reduce_kernel finishes
+    float* part = p.partial + (int64_t)kslice * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + r16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int nb = n0 + wc * 64 + j * 16 + 4 * g;
+        float* o = part + (int64_t)m * p.N + nb;
+        if (nb + 3 < p.N && (p.N & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        else for (int rr = 0; rr < 4; ++rr) if (nb + rr < p.N) o[rr] = acc[i][j][rr];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wr * 128 + i * 16 + r16;
@@ -195,14 +219,51 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   }
 }
 
+// C = epilogue(sum_s partial[s]) with the epilogue of the GEMM kernels: (+bias), (bf16 round, +res),
+// bf16 or fp32 (optionally accumulated) output.  4 columns per thread.
+__global__ __launch_bounds__(256) void gemm8_reduce_kernel(Gemm8Args p) {
+  const int64_t q4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = (p.N + 3) >> 2;
+  if (q4 >= (int64_t)p.M * n4) return;
+  const int m = (int)(q4 / n4), nb = (int)(q4 - (int64_t)m * n4) * 4;
+  float y[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool vec = (nb + 3 < p.N) && ((p.N & 3) == 0);
+  for (int s = 0; s < p.ksplit; ++s) {
+    const float* src = p.partial + ((int64_t)s * p.M + m) * p.N + nb;
+    if (vec) { const float4 v = *reinterpret_cast<const float4*>(src); y[0] += v.x; y[1] += v.y; y[2] += v.z; y[3] += v.w; }
+    else for (int rr = 0; rr < 4; ++rr) if (nb + rr < p.N) y[rr] += src[rr];
+  }
+  for (int rr = 0; rr < 4; ++rr) {
+    const int n = nb + rr;
+    if (n >= p.N) break;
+    float v = y[rr];
+    if (p.bias) v += bf2f(p.bias[n]);
+    if (p.res) v = rbf(v) + bf2f(p.res[(int64_t)m * p.ldr + n]);
+    if (p.out_f32) { float* o = (float*)p.C + (int64_t)m * p.ldc + n; *o = p.accumulate ? *o + v : v; }
+    else { bf16_t* o = (bf16_t*)p.C + (int64_t)m * p.ldc + n; *o = f2bf(p.accumulate ? bf2f(*o) + v : v); }
+  }
+}
+
 // Called by eagle_gemm_nt_bf16 (gemm_mfma.hip) after its argument checks.
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
-                          const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, hipStream_t stream) {
+                          const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
+                          void* workspace, hipStream_t stream) {
   Gemm8Args a;
+  const int nk = K / G8_BK;
+  if (ksplit < 1) ksplit = 1;
+  if (ksplit > nk) ksplit = nk;
+  a.kchunk = (nk + ksplit - 1) / ksplit;
+  a.ksplit = (nk + a.kchunk - 1) / a.kchunk;        // every slice non-empty
+  a.partial = (float*)workspace;
+  if (a.ksplit > 1 && !workspace) return EAGLE_ERR_ARG;
   a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
   a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = (N + G8_BN - 1) / G8_BN;
-  hipLaunchKernelGGL(gemm_nt8_kernel, dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
+  hipLaunchKernelGGL(gemm_nt8_kernel, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
+  int rc = eagle_check_launch();
+  if (rc || a.ksplit == 1) return rc;
+  const int64_t q4 = (int64_t)M * ((N + 3) / 4);
+  hipLaunchKernelGGL(gemm8_reduce_kernel, dim3((unsigned)((q4 + 255) / 256)), dim3(256), 0, stream, a);
   return eagle_check_launch();
 }

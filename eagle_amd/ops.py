@@ -61,8 +61,9 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
 
 
 def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
-            out: Optional[torch.Tensor] = None, out_dtype=BF16, accumulate: bool = False) -> torch.Tensor:
-    """C[M,N] = A[M,K] @ B[N,K]^T (+bias) (+res) on the LDS-tiled MFMA kernel."""
+            out: Optional[torch.Tensor] = None, out_dtype=BF16, accumulate: bool = False, ksplit: int = 1) -> torch.Tensor:
+    """C[M,N] = A[M,K] @ B[N,K]^T (+bias) (+res) on the LDS-tiled MFMA kernels.  ksplit > 1: split-K
+    (few output tiles, very long K: the lm_head dgrad)."""
     _chk(A, "A"), _chk(B, "B")
     M, K = A.shape
     N = B.shape[0]
@@ -74,6 +75,12 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
     if out.dtype not in (BF16, torch.float32) or out.stride(1) != 1:
         raise TypeError("gemm_nt: C must be bf16 or fp32, row-major")
+    if ksplit > 1:
+        ws = _workspace(query("eagle_gemm_nt_splitk_workspace_bytes", M, N, ksplit), A.device)
+        call("eagle_gemm_nt_splitk_bf16", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0), ptr(bias), ptr(res),
+             (res.stride(0) if res is not None else 0), M, N, K, int(out.dtype == torch.float32), int(accumulate), ksplit,
+             ptr(ws), stream())
+        return out
     call("eagle_gemm_nt_bf16", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0), ptr(bias), ptr(res),
          (res.stride(0) if res is not None else 0), M, N, K, int(out.dtype == torch.float32), int(accumulate), stream())
     return out

@@ -194,8 +194,17 @@ def loss_fwd_bwd(predict: torch.Tensor, target: torch.Tensor, lm_head: torch.Ten
         return sums, None
     dlog, dpv = ops.ce_smoothl1_bwd(t_logits, o_logits, lse_t, lse_o, mask, p_w * scale, v_w * scale, predict, target,
                                     in_place=True)
-    dpredict = ops.gemm_nt(dlog, lm_head_t, res=dpv)
+    dpredict = ops.gemm_nt(dlog, lm_head_t, res=dpv, ksplit=lm_dgrad_ksplit(dlog.shape[0], lm_head_t.shape[0], dlog.shape[1]))
     return sums, dpredict
+
+
+def lm_dgrad_ksplit(M: int, N: int, K: int) -> int:
+    """dpredict = dlogits[M,V] . lm_head[V,D] has few 256x256 output tiles (M/256 * D/256) and a very
+    long K = V: split K so that two full rounds of workgroups cover the 256 CUs."""
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if tiles >= 512 or K < 16384:
+        return 1
+    return max(1, min(16, 512 // tiles))
 
 
 # ---------------------------------------------------------------------------------------------

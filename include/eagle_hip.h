@@ -53,6 +53,14 @@ int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int
 int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                        const void* bias, const void* res, int64_t ldr, int M, int N, int K,
                        int out_f32, int accumulate, eagle_stream_t stream);
+/* Split-K form of the above for few output tiles and a very long K -- the lm_head dgrad behind
+ * loss.backward(), eagle/train.py:110,:126 (M = tokens, N = D, K = vocabulary): ksplit K-slices run as
+ * separate workgroups into fp32 partials [ksplit][M][N] in `workspace`, a second launch sums them and
+ * applies the same epilogue.  ksplit <= 1: identical to eagle_gemm_nt_bf16. */
+int64_t eagle_gemm_nt_splitk_workspace_bytes(int M, int N, int ksplit);
+int eagle_gemm_nt_splitk_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                              const void* bias, const void* res, int64_t ldr, int M, int N, int K, int out_f32,
+                              int accumulate, int ksplit, void* workspace, eagle_stream_t stream);
 /* out[C,R_pad] = in[R,C]^T, bf16, columns [R, R_pad) zero-filled (R_pad < R: no padding): operand
  * preparation for the dgrad / wgrad GEMMs behind loss.backward() (eagle/train.py:126); the zero
  * padding lets a token count that is no multiple of 64 serve as the GEMM's K.  ldo >= R_pad. */

@@ -16,7 +16,7 @@ import torch.nn.functional as F
 BF16 = torch.bfloat16
 
 
-def gemm_nt(A, B, bias=None, res=None, out=None, out_dtype=BF16, accumulate=False):
+def gemm_nt(A, B, bias=None, res=None, out=None, out_dtype=BF16, accumulate=False, ksplit=1):
     y = A.float() @ B.float().t()
     if bias is not None:
         y = y + bias.float()

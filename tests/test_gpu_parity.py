@@ -515,6 +515,27 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
         setm(2)
 
 
+@pytest.mark.parametrize("M,N,K,S", [(256, 256, 1024, 4), (300, 130, 64 * 37, 5), (2048, 512, 8192, 4), (64, 64, 128, 8)])
+def test_gemm_nt_split_k(M, N, K, S):
+    """Split-K form (the lm_head dgrad shape: few output tiles, long K) against fp32 torch and the
+    single-pass kernel; bias / residual / fp32 epilogues go through the reduce kernel."""
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + S)
+    A = torch.randn(M, K, generator=g).to(BF)
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
+    res = torch.randn(M, N, generator=g).to(BF)
+    bias = torch.randn(N, generator=g).to(BF)
+    ref = A.float() @ Bm.float().t()
+    y = ops.gemm_nt(A.to(dev()), Bm.to(dev()), ksplit=S)
+    close(y, ref, what="split-k bf16")
+    y1 = ops.gemm_nt(A.to(dev()), Bm.to(dev()))
+    close(y, y1.float(), rtol=4e-3, atol=float(ref.abs().max()) / 128.0, what="split-k vs single pass")
+    y2 = ops.gemm_nt(A.to(dev()), Bm.to(dev()), bias=bias.to(dev()), res=res.to(dev()), ksplit=S)
+    close(y2, (ref + bias.float()).to(BF).float() + res.float(), what="split-k bias+res")
+    yf = ops.gemm_nt(A.to(dev()), Bm.to(dev()), out_dtype=torch.float32, ksplit=S)
+    close(yf, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="split-k fp32")
+
+
 def test_transpose():
     from eagle_amd import ops
     g = torch.Generator().manual_seed(4)
