@@ -152,7 +152,7 @@ def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, pla
 
 
 def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
-    """Dominant kernel: gemm_skinny_kernel<2,1,0> = the lm_head weight stream (one launch per
+    """Dominant kernel: gemm_skinny_keepx_kernel<2,0,4> = the lm_head weight stream (one launch per
     draft-tree step).  Measured IN the cycle, not back to back: `cycles` eager draft/verify cycles
     with a HIP event pair (on the launch stream = torch's current stream) around every lm_head
     launch, so each launch starts behind the down-projection kernel as it does in the timed region
@@ -196,7 +196,7 @@ def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
         with open(pj) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
     n = len(marks)
-    return {"bound": "hbm", "kernel": "gemm_skinny_kernel<2,1,0> (lm_head weight stream, 1-8 rows, in-cycle)",
+    return {"bound": "hbm", "kernel": "gemm_skinny_keepx_kernel<2,0,4> (lm_head weight stream, 1-8 rows, in-cycle)",
             "achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": nbytes / n, "us_per_launch": sec / n * 1e6, "launches_timed": n,

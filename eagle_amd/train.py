@@ -345,7 +345,7 @@ class EagleTrainer:
     def __init__(self, model, lm_head_weight: torch.Tensor, lr: float = 2e-4, betas=(0.9, 0.95), eps: float = 1e-8,
                  weight_decay: float = 0.01, v_w: float = 1.0, p_w: float = 0.1, grad_clip: float = 0.5,
                  num_warmup_steps: Optional[int] = None, num_training_steps: Optional[int] = None, mode: str = "dp",
-                 group=None, world_size: int = 1, sharded_loss: Optional["ShardedLmHeadLoss"] = None, bucket_names: Sequence[Sequence[str]] = (("wdown",), ("wgu", "wn"), ("wo", "wqkv", "fc"))):
+                 group=None, world_size: int = 1, sharded_loss: Optional["ShardedLmHeadLoss"] = None, bucket_names: Sequence[Sequence[str]] = (("wdown",), ("wgu", "wn"), ("wo",), ("wqkv",), ("fc",))):
         if mode not in ("dp", "tp"):
             raise ValueError("mode: 'dp' (eagle/train.py) or 'tp' (eagle/train_tp.py)")
         self.model, self.mode, self.group, self.world = model, mode, group, world_size

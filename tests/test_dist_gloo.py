@@ -166,7 +166,7 @@ def test_bucket_layout_tiles_the_flat_buffer():
         from eagle_amd.train import EagleTrainer, PARAM_ORDER
         dims, wb, model, lm_head = _tiny()
         tr = EagleTrainer(model, lm_head, mode="dp")
-        assert [b[0] for b in tr._buckets] == ["wdown", "wn", "fc"]
+        assert [b[0] for b in tr._buckets] == ["wdown", "wn", "wo", "wqkv", "fc"]
         assert tr._buckets[0][1] == 0 and tr._buckets[-1][2] == tr.flat.numel()
         for name, p in model.named_parameters():
             if p.requires_grad:
