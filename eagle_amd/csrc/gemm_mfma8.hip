@@ -25,6 +25,7 @@
 // LDS image of a half-tile: [128 rows][8 x 16 B], 16-byte chunk XOR (row & 7) -- applied on the
 // per-lane SOURCE address of the DMA (its LDS destination is lane-linear) and on the ds_read side.
 #include "common.h"
+#include <stdlib.h>
 
 #define G8_BM 256
 #define G8_BN 256
@@ -63,6 +64,7 @@ __device__ __forceinline__ void g8_stage(const bf16_t* X, int64_t ld, int nrows,
   }
 }
 
+template <bool PINGPONG, int DBG = 0>
 __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   // ONE shared array (a second LDS object makes hipcc drain the DMA before every ds_read):
   // [buffer 2][A0, A1, B0, B1][128 x 64]  = 128 KB
@@ -131,6 +133,52 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
     acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][s], af[i][s], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);
 
+  if (PINGPONG) {
+    // Ping-pong schedule: the two waves of a SIMD (wr = 0 / wr = 1 share it) run the same program one
+    // barrier apart, so that while one multiplies a quadrant (16 MFMAs) the other issues its LDS
+    // fragment reads and its share of the DMA -- the reads no longer sit in front of the MFMAs of
+    // BOTH waves.  Eight slots per K tile (R = reads/DMA, M = MFMA); group wr=1 enters one barrier late:
+    //   S1 R  B(nh0) B(nh1) A(mh0) reads; stage A0(t+1) -> buffer b^1   S2 M  quadrant (0,0)
+    //   S3 R  stage A1(t+1) -> buffer b^1                               S4 M  quadrant (0,1)
+    //   S5 R  A(mh1) reads; stage B0(t+2) -> buffer b                   S6 M  quadrant (1,1)
+    //   S7 R  stage B1(t+2) -> buffer b; vmcnt(4): tile t+1 landed      S8 M  quadrant (1,0)
+    // Two DMA pieces per R slot: a piece costs its wave ~60-185 issue cycles (MI355X_MICROARCH.md,
+    // 'LDS-DMA piece issue cost'), so four in one slot outlast the partner's 16 MFMAs.
+    // WAR (a region is restaged >= 2 slots after its last read by EITHER group, whose reads retire
+    // at the top of the following M slot): A halves of buffer b^1 were last read in S5(t-1), i.e. 4
+    // (3 for the late group) slots before S1(t); B halves of buffer b are last read in S1(t), 4 (3)
+    // slots before S5(t).  RAW: each wave retires its pieces of tile t+1 at its S7(t); the late group's
+    // S7(t) ends one barrier before the early group's S1(t+1).
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    // DBG (timing experiments only, results invalid): bit 0 = no DMA in the loop, bit 1 = no LDS reads,
+    // bit 2 = no barriers
+#define G8_BAR() do { if (!(DBG & 4)) __builtin_amdgcn_s_barrier(); } while (0)
+    if (DBG & 2) { read_b(hbuf(0, 2 + (wc >> 1)), 0, bf0); read_a(hbuf(0, wr), 0); read_b(hbuf(0, 2 + (wc >> 1)), 1, bf1); }
+    for (int t = 0; t < nk; ++t) {
+      const bf16_t* la = hbuf(t & 1, wr);
+      const bf16_t* lb = hbuf(t & 1, 2 + (wc >> 1));
+      if (!(DBG & 2)) { read_b(lb, 0, bf0); read_a(la, 0); read_b(lb, 1, bf1); }
+      if (!(DBG & 1)) stage_a(0, t + 1);
+      G8_BAR();
+      G8_MFMA(0, 0, bf0)
+      G8_BAR();
+      if (!(DBG & 1)) stage_a(1, t + 1);
+      G8_BAR();
+      G8_MFMA(0, 1, bf1)
+      G8_BAR();
+      if (!(DBG & 2)) read_a(la, 1);
+      if (!(DBG & 1)) stage_b(0, t + 2);
+      G8_BAR();
+      G8_MFMA(1, 1, bf1)
+      G8_BAR();
+      if (!(DBG & 1)) { stage_b(1, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      G8_BAR();
+      G8_MFMA(1, 0, bf0)
+      G8_BAR();
+    }
+#undef G8_BAR
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+  } else
   for (int t = 0; t < nk; ++t) {
     const bf16_t* la = hbuf(t & 1, wr);
     const bf16_t* lb = hbuf(t & 1, 2 + (wc >> 1));
@@ -244,6 +292,9 @@ __global__ __launch_bounds__(256) void gemm8_reduce_kernel(Gemm8Args p) {
   }
 }
 
+static int g_g8_pingpong = -1;     // EAGLE_GEMM8_PINGPONG=0 selects the in-phase schedule (A/B measurements)
+extern "C" void eagle_debug_set_gemm8_pingpong(int on) { g_g8_pingpong = on; }
+
 // Called by eagle_gemm_nt_bf16 (gemm_mfma.hip) after its argument checks.
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                           const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
@@ -260,7 +311,18 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
   a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = (N + G8_BN - 1) / G8_BN;
-  hipLaunchKernelGGL(gemm_nt8_kernel, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
+  if (g_g8_pingpong < 0) { const char* e = getenv("EAGLE_GEMM8_PINGPONG"); g_g8_pingpong = e ? atoi(e) : 1; }
+  if (g_g8_pingpong >= 16) {      // timing experiments (tools/gemm_bench.py): 16 + DBG bits
+    const dim3 gr(a.tiles_m * a.tiles_n * a.ksplit), bl(G8_THREADS);
+    switch (g_g8_pingpong - 16) {
+      case 1: hipLaunchKernelGGL((gemm_nt8_kernel<true, 1>), gr, bl, 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((gemm_nt8_kernel<true, 2>), gr, bl, 0, stream, a); break;
+      case 3: hipLaunchKernelGGL((gemm_nt8_kernel<true, 3>), gr, bl, 0, stream, a); break;
+      case 7: hipLaunchKernelGGL((gemm_nt8_kernel<true, 7>), gr, bl, 0, stream, a); break;
+      default: return EAGLE_ERR_ARG;
+    }
+  } else if (g_g8_pingpong) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL(gemm_nt8_kernel<false>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
   int rc = eagle_check_launch();
   if (rc || a.ksplit == 1) return rc;
   const int64_t q4 = (int64_t)M * ((N + 3) / 4);

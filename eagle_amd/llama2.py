@@ -217,6 +217,11 @@ class Llama2Model(nn.Module):
         emb_w = self.embed_tokens.weight
         if emb_w.dtype != torch.bfloat16:
             raise TypeError("embed_tokens must be bf16 (cast the model with .to(torch.bfloat16))")
+        if emb_ind is not None and M > 64:
+            # wide batches: resolve flat_topk[tree_indices] into a plain id array first (the fused double
+            # indirection of the weight-stream GEMM covers one 64-row pass)
+            emb_idx = ops.tree_gather_ids(emb_idx, emb_ind, B=B, batch_stride=emb_bstride).reshape(-1)
+            emb_ind, emb_bstride = None, 0
         # fc(cat(embed_tokens(ids), hidden)) -- eagle/llama2.py:515, :537-542
         x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
                               ind0=emb_ind, idx0_bstride=emb_bstride)

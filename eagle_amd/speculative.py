@@ -34,6 +34,14 @@ from .tree import TreeBuffers, mc_sim_7b_63
 BF16 = torch.bfloat16
 
 
+class _CacheRows:
+    """One request's rows of the batched draft KV cache (same strides, batch extent 1)."""
+    __slots__ = ("k", "v")
+
+    def __init__(self, k, v):
+        self.k, self.v = k, v
+
+
 class EagleDrafter:
     def __init__(self, model: Llama2Model, lm_head_weight: torch.Tensor, tree: Sequence[Sequence[int]] = mc_sim_7b_63,
                  expand: str = "wchild", batch: int = 1, max_ctx: int = 2048, topk: int = 10):
@@ -61,7 +69,8 @@ class EagleDrafter:
         self.flat_vals = torch.zeros((B, self.R, topk), dtype=BF16, device=dev)
         self._rowbase = torch.arange(B, dtype=torch.int64, device=dev) * self.W
         rows_max = B * max(self.W, self.tb.n_nodes, 16)
-        self._ws = torch.empty(ops.query("eagle_topk_workspace_bytes", rows_max, V, topk), dtype=torch.uint8, device=dev)
+        self._ws = torch.empty(max(ops.query("eagle_topk_workspace_bytes", rows_max, V, topk),
+                                   ops.query("eagle_lm_head_topk_workspace_bytes", rows_max, V, topk)), dtype=torch.uint8, device=dev)
         ar_b = torch.arange(B, dtype=torch.int64, device=dev)[:, None]
         self._hid_idx, prev_n = [], 1
         for s in self.tb.steps:                               # static batch-major parent-row gathers
@@ -89,11 +98,11 @@ class EagleDrafter:
     # -------------------------------------------------------------- draft side
     def _head_topk(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int, row0: int, n: int):
         """top-k(lm_head(x[idx])) -> flat rows [row0, row0+n) of every request."""
-        logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
         if self.B == 1:
-            ops.topk(logits, self.k, out_idx=self.flat_ids[0, row0:row0 + n], out_val=self.flat_vals[0, row0:row0 + n],
-                     workspace=self._ws)
+            ops.lm_head_topk(x, self.lm_head, self.k, idx0=idx, M=rows, out_idx=self.flat_ids[0, row0:row0 + n],
+                             out_val=self.flat_vals[0, row0:row0 + n], workspace=self._ws)
         else:
+            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
             vals, ids = ops.topk(logits, self.k, workspace=self._ws)
             self.flat_ids[:, row0:row0 + n] = ids.view(self.B, n, self.k)
             self.flat_vals[:, row0:row0 + n] = vals.view(self.B, n, self.k)
@@ -113,6 +122,31 @@ class EagleDrafter:
         last = torch.arange(B, dtype=torch.int64, device=self.dev) * ctx + (ctx - 1)
         self._head_topk(x, last, B, 0, 1)
         self._expand(x, last[:, None].expand(B, self.n0).reshape(-1).contiguous())
+        return self.flat_ids, self.flat_vals
+
+    def prefill_ragged(self, hiddens: Sequence[torch.Tensor], input_ids: Sequence[torch.Tensor]):
+        """First call of a batch of requests with DIFFERENT prompt lengths (BASELINE configs[3]:
+        ShareGPT-length prompts): hiddens[b] [ctx_b, D], input_ids[b] [ctx_b + 1].  Each prompt is
+        run through the draft head into its own rows of the batched KV cache (per-request lengths
+        live on the device from here on); the tree expansion that follows is batched."""
+        B, m = self.B, self.model
+        if len(hiddens) != B or len(input_ids) != B:
+            raise ValueError(f"expected {B} requests")
+        lastx = torch.empty((B, self.D), dtype=BF16, device=self.dev)
+        self.len_cur.zero_()
+        for b in range(B):
+            h, ids = hiddens[b], input_ids[b].reshape(-1)
+            ctx = h.shape[0]
+            if h.dim() != 2 or ids.numel() != ctx + 1 or ctx < 1 or ctx + self.W + self.n_fwd > self.cap:
+                raise ValueError(f"request {b}: hidden [ctx, D], ids [ctx+1], ctx within the cache capacity")
+            views = [_CacheRows(c.k[b:b + 1], c.v[b:b + 1]) for c in self.caches]
+            x = m._forward_rows(ids[1:].contiguous(), h.contiguous(), None, ctx, 1, ctx, None, self.len_cur[b:b + 1],
+                                None, None, None, views, past_host=0)
+            lastx[b].copy_(x[ctx - 1])
+            self.len_nxt[b:b + 1].fill_(ctx)
+        rows = torch.arange(B, dtype=torch.int64, device=self.dev)
+        self._head_topk(lastx, rows, B, 0, 1)
+        self._expand(lastx, rows[:, None].expand(B, self.n0).reshape(-1).contiguous())
         return self.flat_ids, self.flat_vals
 
     def set_accepted(self, n_acc: torch.Tensor):

@@ -10,19 +10,21 @@ import ctypes
 from eagle_amd import _hip
 setm = _hip.lib().eagle_debug_set_gemm8
 setm.argtypes, setm.restype = [ctypes.c_int], None
+setpp = _hip.lib().eagle_debug_set_gemm8_pingpong
+setpp.argtypes, setpp.restype = [ctypes.c_int], None
 for M, N, K, name in shapes:
     A = torch.randn(M, K, device=dev).to(torch.bfloat16); B = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     it = 10
-    for mode in (0, 1):
-        setm(mode)
+    for mode, pp in ((0, 0), (1, 0), (1, 1)):
+        setm(mode); setpp(pp)
         for _ in range(3): ops.gemm_nt(A, B, out=C)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(it): ops.gemm_nt(A, B, out=C)
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / it
-        print(f"{name:16s} M={M} N={N} K={K} [{'256x256 8-phase' if mode else '128x128       '}]: {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
+        print(f"{name:16s} M={M} N={N} K={K} [{('256x256 ping-pong' if pp else '256x256 in-phase ') if mode else '128x128          '}]: {ms*1e3:9.1f} us  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
     setm(2)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record(); 
