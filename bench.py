@@ -239,6 +239,37 @@ def cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, expand, max_
                       f"bf16 torch CPU oracle, batch 1, ctx~{hidden.shape[1]}"}
 
 
+def cpu_train_baseline(config: str = "qwen3_8b", L: int = 256, max_seconds: float = 25.0) -> dict:
+    """CPU oracle (oracle/train_step.py, torch autograd, 'port') on a BOUNDED sample of the same
+    workload: one micro-batch of 1 x L tokens (L = 256 instead of 2048: a full-length step takes
+    minutes on the host), forward + fused loss + backward + AdamW, bf16, reported in tokens/s."""
+    from oracle import draft_model as dm
+    from oracle import train_step as ots
+
+    from eagle_amd.config import DraftConfig, LLAMA2_7B_DRAFT, QWEN3_8B_DRAFT
+    cfg = DraftConfig(**(QWEN3_8B_DRAFT if config == "qwen3_8b" else LLAMA2_7B_DRAFT))
+    BF16 = torch.bfloat16
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    dims = dm.DraftDims(hidden=cfg.hidden_size, inter=cfg.intermediate_size, heads=cfg.num_attention_heads,
+                        kv_heads=cfg.num_key_value_heads, vocab=cfg.vocab_size)
+    w = {k: v.to(BF16) for k, v in dm.init_weights(dims, seed=0, std=0.02).items()}
+    g = torch.Generator().manual_seed(1)
+    lm_head = (torch.randn(dims.vocab, dims.hidden, generator=g) * 0.02).to(BF16)
+    mb = {"hidden_states": torch.randn(1, L, dims.hidden, generator=g).to(BF16),
+          "target": torch.randn(1, L, dims.hidden, generator=g).to(BF16),
+          "input_ids": torch.randint(0, dims.vocab, (1, L), generator=g),
+          "loss_mask": torch.ones(1, L, dtype=torch.int64)}
+    state: dict = {}
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or (time.perf_counter() - t0 < max_seconds and n < 4):
+        ots.optimizer_step(w, dims, lm_head, [[mb]], state, mode="dp", lr=2e-4, betas=(0.9, 0.95), clip=0.5, v_w=1.0, p_w=0.1)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * L / dt, "unit": "loss tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} optimizer steps of one 1x{L}-token micro-batch (the GPU leg runs 1x2048), bf16 torch CPU oracle "
+                      "(forward + loss + autograd backward + AdamW)"}
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -320,6 +351,8 @@ def main():
         torch.cuda.empty_cache()
         tr = train_tokens_per_s(dev, rank, world, dist, steps=a.train_steps, warmup=a.train_warmup)
         if rank == 0 and tr is not None:
+            if world == 1 and not a.no_cpu_baseline:
+                tr["cpu_baseline"] = cpu_train_baseline()
             out["train"] = tr
     if rank == 0:
         print(json.dumps(out), flush=True)

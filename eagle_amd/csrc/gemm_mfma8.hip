@@ -92,7 +92,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   const int nk_all = p.K / G8_BK;
   const int kt0 = kslice * p.kchunk;
   const int nk = min(p.kchunk, nk_all - kt0);       // K tiles of this slice (>= 1: launcher)
-  auto kt_of = [&](int t) { return kt0 + (t < nk ? t : nk - 1); };
+  auto kt_of = [&](int t) { return (DBG & 8) ? kt0 + (t & 1) : kt0 + (t < nk ? t : nk - 1); };
   auto hbuf = [&](int buf, int which) { return lds + (buf * 4 + which) * G8_HALF; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
   auto stage_a = [&](int h, int t) { g8_stage(p.A, p.lda, p.M, m0, h, kt_of(t), hbuf(t & 1, h), tid); };
   auto stage_b = [&](int h, int t) { g8_stage(p.B, p.ldb, p.N, n0, h, kt_of(t), hbuf(t & 1, 2 + h), tid); };
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
     // S7(t) ends one barrier before the early group's S1(t+1).
     if (wr == 1) __builtin_amdgcn_s_barrier();
     // DBG (timing experiments only, results invalid): bit 0 = no DMA in the loop, bit 1 = no LDS reads,
-    // bit 2 = no barriers
+    // bit 2 = no barriers, bit 3 = DMA always from the first two K tiles (cache-hot), bit 4 = no vmcnt wait
 #define G8_BAR() do { if (!(DBG & 4)) __builtin_amdgcn_s_barrier(); } while (0)
     if (DBG & 2) { read_b(hbuf(0, 2 + (wc >> 1)), 0, bf0); read_a(hbuf(0, wr), 0); read_b(hbuf(0, 2 + (wc >> 1)), 1, bf1); }
     for (int t = 0; t < nk; ++t) {
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
       G8_BAR();
       G8_MFMA(1, 1, bf1)
       G8_BAR();
-      if (!(DBG & 1)) { stage_b(1, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+      if (!(DBG & 1)) { stage_b(1, t + 2); if (!(DBG & 16)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
       G8_BAR();
       G8_MFMA(1, 0, bf0)
       G8_BAR();
@@ -319,6 +319,9 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
       case 2: hipLaunchKernelGGL((gemm_nt8_kernel<true, 2>), gr, bl, 0, stream, a); break;
       case 3: hipLaunchKernelGGL((gemm_nt8_kernel<true, 3>), gr, bl, 0, stream, a); break;
       case 7: hipLaunchKernelGGL((gemm_nt8_kernel<true, 7>), gr, bl, 0, stream, a); break;
+      case 8: hipLaunchKernelGGL((gemm_nt8_kernel<true, 8>), gr, bl, 0, stream, a); break;
+      case 16: hipLaunchKernelGGL((gemm_nt8_kernel<true, 16>), gr, bl, 0, stream, a); break;
+      case 24: hipLaunchKernelGGL((gemm_nt8_kernel<true, 24>), gr, bl, 0, stream, a); break;
       default: return EAGLE_ERR_ARG;
     }
   } else if (g_g8_pingpong) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);

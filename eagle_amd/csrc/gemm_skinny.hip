@@ -15,7 +15,6 @@
 //   * the activation row can be the concatenation of two gathered sources:
 //     fc(cat(embed_tokens[ids], hidden[parent_row]))  (eagle/llama2.py:515, :542).
 #include "common.h"
-#include "topk_keys.h"
 #include <stdlib.h>
 
 #define SK_WAVES 8
@@ -31,12 +30,7 @@ struct SkinnyArgs {
   const bf16_t* bias; const bf16_t* res; int64_t ldr;
   bf16_t* out; int64_t ldo;
   int M, N, K;
-  // keepx kernel, EPI_LINEAR only: stage 1 of the vocabulary top-k from the epilogue.  Every workgroup
-  // leaves the k best (value desc, index asc) of its own row range per token in
-  // topk_cand[(m * gridDim.x + blockIdx.x) * topk_k + r], in topk.hip's 64-bit candidate format.
-  unsigned long long* topk_cand; int topk_k;
 };
-#define SK_TOPK_MAXR 640     // rows per workgroup the fused top-k can hold in LDS (V = 151936 / 256 CUs = 596)
 
 template <int RT, int MT, int EPI>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
@@ -436,11 +430,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
 // for all of the block's rows (no per-tile-step re-read of x through L2: at 8 tokens that re-read
 // is half as many bytes again as the weight stream), the RMSNorm row statistics are computed once,
 // and the super-step loop is fully unrolled: stage parity, x fragment and refill target are static.
-template <int RT, int EPI, int NI, bool TOPK = false>
+template <int RT, int EPI, int NI>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
   static_assert((NI & 1) == 0, "two register stages alternate");
-  static_assert(!TOPK || EPI == EPI_LINEAR, "top-k candidates come from plain logits");
-  __shared__ __attribute__((aligned(16))) bf16_t lg[TOPK ? 16 * SK_TOPK_MAXR : 8];   // [token][row - row_lo] logits of this block
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;
   constexpr int RPS = RTW * 16;
   __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][RT][64][4];
@@ -567,47 +559,6 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
           } else {
             for (int r = 0; r < 4; ++r) if (nb + r < row_hi) o[r] = f2bf(y[r]);
           }
-          if (TOPK) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (nb + r < row_hi) lg[m * SK_TOPK_MAXR + (nb + r - row_lo)] = f2bf(y[r]);
-          }
-        }
-      }
-    }
-  }
-  if (TOPK) {
-    // stage 1 of the top-k over this block's rows: wave w takes tokens w and w + 8; 32-bit keys =
-    // 16-bit monotone value | (1023 - local row), k rounds of a DPP wave maximum (topk.hip)
-    __syncthreads();
-    const int nrow = row_hi - row_lo;
-    constexpr int PL = (SK_TOPK_MAXR + 63) / 64;
-    for (int m = wave; m < p.M; m += SK_WAVES) {
-      uint32_t key[PL];
-      uint32_t best = 0;
-#pragma unroll
-      for (int j = 0; j < PL; ++j) {
-        const int loc = lane + 64 * j;
-        key[j] = loc < nrow ? ((mono_bf16(lg[m * SK_TOPK_MAXR + loc]) << 16) | (uint32_t)(1023 - loc)) : 0u;
-        best = key[j] > best ? key[j] : best;
-      }
-      unsigned long long* outc = p.topk_cand + ((int64_t)m * gridDim.x + blockIdx.x) * p.topk_k;
-      for (int r = 0; r < p.topk_k; ++r) {
-        const uint32_t bm = wave_umax(best);
-        if (lane == 0) {
-          unsigned long long o = 0;
-          if (bm) {
-            const uint32_t gidx = (uint32_t)row_lo + (1023u - (bm & 0xffffu));
-            o = ((unsigned long long)(bm & 0xffff0000u) << 32) | (unsigned long long)(0xffffffffu - gidx);
-          }
-          outc[r] = o;
-        }
-        if (bm != 0 && best == bm) {
-          best = 0;
-#pragma unroll
-          for (int j = 0; j < PL; ++j) {
-            if (key[j] == bm) key[j] = 0;
-            best = key[j] > best ? key[j] : best;
-          }
         }
       }
     }
@@ -712,7 +663,6 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     a.res = res ? (const bf16_t*)res + (int64_t)m0 * ldr : nullptr; a.ldr = ldr;
     a.out = (bf16_t*)out + (int64_t)m0 * ldo; a.ldo = ldo;
     a.M = mc; a.N = N; a.K = K;
-    a.topk_cand = nullptr; a.topk_k = 0;
     int rc;
     const int var = skinny_variant();   // 3 = per-shape choice (measured); 0/1/2 force one kernel family
     const bool big = (epi == EPI_SILU_MUL) || N >= 8192;
@@ -738,65 +688,4 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     if (rc) return rc;
   }
   return EAGLE_OK;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// lm_head + top-k in one weight pass (the per-depth step of the expansion loop):
-// logits = x[idx0] . W^T as above, and the k largest logits per row (value desc, index asc).
-// With <= 16 rows and K = 4096 the weight-stream kernel emits the stage-1 candidates from its
-// epilogue (k per workgroup and row), so the separate scan of the logits disappears; other shapes
-// run the plain GEMM followed by eagle_topk_vocab.  Bit-exact either way: the candidates are taken
-// from the same bf16 logits that are written out.
-// ---------------------------------------------------------------------------------------------
-int eagle_launch_topk_stage2_bf16(const unsigned long long* cand, int ncand, int k, const void* logits, int64_t ld, int rows,
-                                  int64_t* out_idx, void* out_val, hipStream_t stream);
-extern "C" int64_t eagle_topk_workspace_bytes(int rows, int V, int k);
-extern "C" int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V, int k, int64_t* out_idx,
-                                void* out_val, void* workspace, const int64_t* block_index, int64_t block_rows,
-                                hipStream_t stream);
-
-static bool lm_head_fused_plan(int M, int N, int K, int k, int* grid_out, int* R_out) {
-  if (M > 16 || K != 128 * SK_WAVES * 4 || k > 16) return false;
-  int grid = sk_num_cus();
-  int R = (N + grid - 1) / grid;
-  if (R < 16) R = 16;
-  R = (R + 3) & ~3;
-  grid = (N + R - 1) / R;
-  if (R > SK_TOPK_MAXR || R > 1024 || (int64_t)grid * k > 256 * 12) return false;
-  *grid_out = grid; *R_out = R;
-  return true;
-}
-
-extern "C" int64_t eagle_lm_head_topk_workspace_bytes(int M, int N, int k) {
-  const int64_t fused = (int64_t)(M < 16 ? 16 : M) * (sk_num_cus() + 1) * k * 8;
-  const int64_t plain = eagle_topk_workspace_bytes(M, N, k);
-  return fused > plain ? fused : plain;
-}
-
-extern "C" int eagle_lm_head_topk_bf16(const void* x, const int64_t* idx0, int64_t ldx, const void* W, void* logits,
-                                       int64_t ldl, int M, int N, int K, int k, int64_t* out_idx, void* out_val,
-                                       void* workspace, hipStream_t stream) {
-  if (!x || !W || !logits || !out_idx || !workspace) return EAGLE_ERR_ARG;
-  if (M < 1 || N < 1 || K < 32 || (K & 31) || k < 1 || k > 16 || ldl < N) return EAGLE_ERR_SHAPE;
-  int grid = 0, R = 0;
-  if (skinny_variant() == 3 && lm_head_fused_plan(M, N, K, k, &grid, &R)) {
-    if ((ldx & 7) || !al16(x) || !al16(W) || (ldx < K && !idx0 && M > 1)) return EAGLE_ERR_SHAPE;
-    SkinnyArgs a;
-    a.x0 = (const bf16_t*)x; a.idx0 = idx0; a.ld0 = ldx; a.K0 = K;
-    a.ind0 = nullptr; a.ind_n = 0; a.idx0_bstride = 0; a.norm_eps = 0.f;
-    a.x1 = nullptr; a.idx1 = nullptr; a.ld1 = 0;
-    a.W = (const bf16_t*)W; a.W2 = nullptr; a.bias = nullptr; a.res = nullptr; a.ldr = 0;
-    a.out = (bf16_t*)logits; a.ldo = ldl; a.M = M; a.N = N; a.K = K;
-    a.topk_cand = (unsigned long long*)workspace; a.topk_k = k;
-    if (N >= 8192) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<2, EPI_LINEAR, 4, true>), dim3(grid), dim3(SK_WAVES * 64), 0, stream, a, R);
-    else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<1, EPI_LINEAR, 4, true>), dim3(grid), dim3(SK_WAVES * 64), 0, stream, a, R);
-    int rc = eagle_check_launch();
-    if (rc) return rc;
-    return eagle_launch_topk_stage2_bf16(a.topk_cand, grid * k, k, logits, ldl, M, out_idx, out_val, stream);
-  }
-  int rc = eagle_gemm_skinny_bf16(x, idx0, ldx, K, nullptr, 0, 0, 0.f, nullptr, nullptr, 0, W, nullptr, nullptr, nullptr, 0,
-                                  logits, ldl, M, N, K, EPI_LINEAR, stream);
-  if (rc) return rc;
-  return eagle_topk_vocab(logits, ldl, 0, M, N, k, out_idx, out_val, workspace, nullptr, 0, stream);
 }

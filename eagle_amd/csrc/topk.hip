@@ -14,14 +14,41 @@
 //   stage 2: one workgroup per row: each wave reduces its share of the candidates to k, wave 0
 //            merges the 4 x k survivors and writes ids (int64) and values.
 #include "common.h"
-#include "topk_keys.h"
 
 #define TK_THREADS 256
 #define TK_WCHUNK 1024                 // logits per wave in stage 1
 #define TK_PER_LANE (TK_WCHUNK / 64)   // 16
 #define TK_MAXK 16
 #define TK_CM 8                        // stage-2 candidates per thread -> wavechunks*k <= 2048
-#define TK_CM_WIDE 12                  // ... <= 3072: one k-tuple per workgroup of the fused lm_head GEMM (<= 256 x k)
+
+__device__ __forceinline__ uint32_t mono_bf16(bf16_t b) {  // 16-bit monotone key in the low half
+  if ((b & 0x7fff) > 0x7f80) return 0xffffu;       // NaN: largest
+  if (b == 0x8000) b = 0;                          // -0.0 == +0.0
+  return (b & 0x8000) ? (uint32_t)(uint16_t)~b : (uint32_t)(b | 0x8000);
+}
+__device__ __forceinline__ uint32_t mono_f32(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+  if (u == 0x80000000u) u = 0;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// full-wave unsigned max, result uniform (read from lane 63)
+__device__ __forceinline__ uint32_t wave_umax(uint32_t v) {
+  uint32_t t;
+  t = __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, false); v = v > t ? v : t;   // quad_perm [1,0,3,2]
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, false); v = v > t ? v : t;   // quad_perm [2,3,0,1]
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xf, 0xf, false); v = v > t ? v : t;  // row_half_mirror
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xf, 0xf, false); v = v > t ? v : t;  // row_mirror
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false); v = v > t ? v : t;  // row_bcast15 -> rows 1,3
+  t = __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false); v = v > t ? v : t;  // row_bcast31 -> rows 2,3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) {
+  const uint32_t hi = wave_umax((uint32_t)(v >> 32));
+  const uint32_t lo = wave_umax(((uint32_t)(v >> 32) == hi) ? (uint32_t)v : 0u);
+  return ((unsigned long long)hi << 32) | lo;
+}
 
 // ---- stage 1, bf16: 32-bit keys ----
 __global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, int k,
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_f32_kernel(const float
   }
 }
 
-template <typename T, int CM>
+template <typename T>
 __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
                                                                 const T* __restrict__ x, int64_t ld,
                                                                 int64_t* __restrict__ out_idx, T* __restrict__ out_val,
@@ -123,22 +150,22 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
   __shared__ unsigned long long surv[4 * TK_MAXK];
   if (block_index) x += *block_index * block_rows * ld;
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  unsigned long long key[CM];
+  unsigned long long key[TK_CM];
 #pragma unroll
-  for (int i = 0; i < CM; ++i) {
+  for (int i = 0; i < TK_CM; ++i) {
     const int c = t + i * TK_THREADS;
     key[i] = c < ncand ? cand[(int64_t)row * ncand + c] : 0ull;
   }
   unsigned long long best = 0;
 #pragma unroll
-  for (int i = 0; i < CM; ++i) best = key[i] > best ? key[i] : best;
+  for (int i = 0; i < TK_CM; ++i) best = key[i] > best ? key[i] : best;
   for (int r = 0; r < k; ++r) {
     const unsigned long long bm = wave_umax64(best);
     if (lane == 0) surv[wave * TK_MAXK + r] = bm;
     if (bm != 0 && best == bm) {
       best = 0;
 #pragma unroll
-      for (int i = 0; i < CM; ++i) {
+      for (int i = 0; i < TK_CM; ++i) {
         if (key[i] == bm) key[i] = 0;
         best = key[i] > best ? key[i] : best;
       }
@@ -180,27 +207,14 @@ extern "C" int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int r
   dim3 g1((nwc + 3) / 4, rows);
   if (dtype == 0) {
     hipLaunchKernelGGL(topk_stage1_bf16_kernel, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand, block_index, block_rows);
-    hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, TK_CM>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+    hipLaunchKernelGGL(topk_stage2_kernel<bf16_t>, dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                        (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows);
   } else if (dtype == 1) {
     hipLaunchKernelGGL(topk_stage1_f32_kernel, g1, dim3(TK_THREADS), 0, stream, (const float*)logits, ld, V, k, nwc, cand, block_index, block_rows);
-    hipLaunchKernelGGL((topk_stage2_kernel<float, TK_CM>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+    hipLaunchKernelGGL(topk_stage2_kernel<float>, dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                        (const float*)logits, ld, out_idx, (float*)out_val, block_index, block_rows);
   } else {
     return EAGLE_ERR_ARG;
   }
-  return eagle_check_launch();
-}
-
-// Stage 2 alone, over candidates produced elsewhere (the fused lm_head GEMM epilogue, gemm_skinny.hip).
-int eagle_launch_topk_stage2_bf16(const unsigned long long* cand, int ncand, int k, const void* logits, int64_t ld, int rows,
-                                  int64_t* out_idx, void* out_val, hipStream_t stream) {
-  if (k < 1 || k > TK_MAXK || ncand > TK_THREADS * TK_CM_WIDE) return EAGLE_ERR_SHAPE;
-  if (ncand <= TK_THREADS * TK_CM)
-    hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, TK_CM>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, ncand, k,
-                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, (const int64_t*)nullptr, (int64_t)0);
-  else
-    hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, TK_CM_WIDE>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, ncand, k,
-                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, (const int64_t*)nullptr, (int64_t)0);
   return eagle_check_launch();
 }

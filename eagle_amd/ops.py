@@ -306,35 +306,6 @@ def topk(logits: torch.Tensor, k: int, want_values: bool = True,
     return (out_val if want_values else None), out_idx
 
 
-def lm_head_topk(x: torch.Tensor, W: torch.Tensor, k: int, idx0: Optional[torch.Tensor] = None, M: Optional[int] = None,
-                 out_idx: Optional[torch.Tensor] = None, out_val: Optional[torch.Tensor] = None,
-                 workspace: Optional[torch.Tensor] = None, logits: Optional[torch.Tensor] = None):
-    """(logits [M,V], values [M,k], indices [M,k]) = lm_head on rows x[idx0] and their top-k (value desc,
-    index asc) in one weight pass (see include/eagle_hip.h: eagle_lm_head_topk_bf16)."""
-    _chk(x, "x"), _chk(W, "W")
-    V, K = W.shape
-    if x.shape[-1] != K or x.stride(-1) != 1 or not W.is_contiguous():
-        raise ValueError("lm_head_topk: x [*, K] rows and W [V, K] contiguous along K")
-    if idx0 is not None and (idx0.dtype != torch.int64 or not idx0.is_contiguous()):
-        raise TypeError("row index arrays must be contiguous int64")
-    if M is None:
-        M = idx0.numel() if idx0 is not None else x.shape[0]
-    dev = x.device
-    if logits is None:
-        logits = torch.empty((M, V), dtype=BF16, device=dev)
-    if out_idx is None:
-        out_idx = torch.empty((M, k), dtype=torch.int64, device=dev)
-    if out_val is None:
-        out_val = torch.empty((M, k), dtype=BF16, device=dev)
-    if not (out_idx.is_contiguous() and out_val.is_contiguous() and out_idx.dtype == torch.int64 and out_val.dtype == BF16):
-        raise TypeError("lm_head_topk: out_idx int64 [M,k] and out_val bf16 [M,k], contiguous")
-    nb = query("eagle_lm_head_topk_workspace_bytes", M, V, k)
-    ws = workspace if workspace is not None and workspace.numel() >= nb else _workspace(nb, dev)
-    call("eagle_lm_head_topk_bf16", ptr(x), ptr(idx0), x.stride(0) if x.dim() > 1 else K, ptr(W), ptr(logits), logits.stride(0),
-         M, V, K, k, ptr(out_idx), ptr(out_val), ptr(ws), stream())
-    return logits, out_val, out_idx
-
-
 def first_argmax(logits: torch.Tensor) -> torch.Tensor:
     return topk(logits, 1, want_values=False)[1][:, 0]
 

@@ -69,8 +69,7 @@ class EagleDrafter:
         self.flat_vals = torch.zeros((B, self.R, topk), dtype=BF16, device=dev)
         self._rowbase = torch.arange(B, dtype=torch.int64, device=dev) * self.W
         rows_max = B * max(self.W, self.tb.n_nodes, 16)
-        self._ws = torch.empty(max(ops.query("eagle_topk_workspace_bytes", rows_max, V, topk),
-                                   ops.query("eagle_lm_head_topk_workspace_bytes", rows_max, V, topk)), dtype=torch.uint8, device=dev)
+        self._ws = torch.empty(ops.query("eagle_topk_workspace_bytes", rows_max, V, topk), dtype=torch.uint8, device=dev)
         ar_b = torch.arange(B, dtype=torch.int64, device=dev)[:, None]
         self._hid_idx, prev_n = [], 1
         for s in self.tb.steps:                               # static batch-major parent-row gathers
@@ -98,11 +97,11 @@ class EagleDrafter:
     # -------------------------------------------------------------- draft side
     def _head_topk(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int, row0: int, n: int):
         """top-k(lm_head(x[idx])) -> flat rows [row0, row0+n) of every request."""
+        logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
         if self.B == 1:
-            ops.lm_head_topk(x, self.lm_head, self.k, idx0=idx, M=rows, out_idx=self.flat_ids[0, row0:row0 + n],
-                             out_val=self.flat_vals[0, row0:row0 + n], workspace=self._ws)
+            ops.topk(logits, self.k, out_idx=self.flat_ids[0, row0:row0 + n], out_val=self.flat_vals[0, row0:row0 + n],
+                     workspace=self._ws)
         else:
-            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
             vals, ids = ops.topk(logits, self.k, workspace=self._ws)
             self.flat_ids[:, row0:row0 + n] = ids.view(self.B, n, self.k)
             self.flat_vals[:, row0:row0 + n] = vals.view(self.B, n, self.k)

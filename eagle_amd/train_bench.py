@@ -16,6 +16,45 @@ import torch
 
 BF16 = torch.bfloat16
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s achievable)
+
+
+def loss_roofline(dev, N: int, V: int, D: int, iters: int = 8) -> dict:
+    """The fused smooth-L1 + soft-label CE kernels alone (HBM-bound): HIP events on the
+    launch stream around `iters` forward launches (ce_partial + ce_combine) and `iters` backward
+    launches (ce_bwd), logits of the training shape already in HBM.  Algorithmic bytes: forward reads
+    both logit tensors once plus predict/target (2*N*V*2 + 2*N*D*2); backward reads both again and
+    writes dlogits and dpredict (3*N*V*2 + 3*N*D*2)."""
+    from . import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    t_logits = (torch.randn((N, V), generator=g, device=dev, dtype=torch.float32) * 2).to(BF16)
+    o_logits = (torch.randn((N, V), generator=g, device=dev, dtype=torch.float32) * 2).to(BF16)
+    predict = torch.randn((N, D), generator=g, device=dev, dtype=torch.float32).to(BF16)
+    target = torch.randn((N, D), generator=g, device=dev, dtype=torch.float32).to(BF16)
+    mask = torch.ones(N, dtype=torch.float32, device=dev)
+
+    def fwd():
+        stats = ops.ce_partial(t_logits, o_logits, 0, predict, target)
+        return ops.ce_combine(stats, mask)
+
+    sums, lse_t, lse_o, _ = fwd()
+    ops.ce_smoothl1_bwd(t_logits, o_logits, lse_t, lse_o, mask, 0.1 / N, 1.0 / N, predict, target)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ev[0].record()
+    for _ in range(iters):
+        fwd()
+    ev[1].record()
+    for _ in range(iters):
+        ops.ce_smoothl1_bwd(t_logits, o_logits, lse_t, lse_o, mask, 0.1 / N, 1.0 / N, predict, target)
+    ev[2].record()
+    torch.cuda.synchronize()
+    t_f, t_b = ev[0].elapsed_time(ev[1]) / iters * 1e-3, ev[1].elapsed_time(ev[2]) / iters * 1e-3
+    b_f, b_b = 2.0 * N * V * 2 + 2.0 * N * D * 2, 3.0 * N * V * 2 + 3.0 * N * D * 2
+    ach = (b_f + b_b) / (t_f + t_b) / 1e9
+    return {"bound": "hbm", "kernel": "ce_partial_kernel + ce_combine_kernel (fwd), ce_bwd_kernel (bwd)", "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "fwd": {"us": t_f * 1e6, "bytes": b_f, "GB/s": b_f / t_f / 1e9}, "bwd": {"us": t_b * 1e6, "bytes": b_b, "GB/s": b_b / t_b / 1e9},
+            "shape": {"N": N, "V": V, "D": D}, "timing": "HIP events around %d back-to-back launches each" % iters}
 
 
 def flops_per_token(cfg, L: int) -> float:
@@ -95,4 +134,7 @@ def train_tokens_per_s(dev, rank: int, world: int, dist, steps: int = 6, warmup:
                          "accuracy": float(sums[2] / sums[3])}}
     del tr, model, lm_head, pool
     torch.cuda.empty_cache()
+    if rank == 0:
+        res["loss_roofline"] = loss_roofline(dev, L, cfg.vocab_size, cfg.hidden_size)
+        torch.cuda.empty_cache()
     return res

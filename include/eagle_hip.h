@@ -139,19 +139,6 @@ int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V,
                      int64_t* out_idx, void* out_val, void* workspace, const int64_t* block_index,
                      int64_t block_rows, eagle_stream_t stream);
 
-/* lm_head + top-k in one weight pass: logits[M,N] = x[idx0 ? idx0[m] : m][0:K] . W[N,K]^T (bf16, written
- * out as by eagle_gemm_skinny_bf16) and the k largest logits of every row in eagle_topk_vocab's order.
- * Replaces the per-depth `last_headout = lm_head(out_hidden)` + `torch.topk(last_headout, top_k)` pair
- * of the expansion loop (frozen head: eagle/train.py:215-228; top_k: eagle/llama2.py:11).
- * With M <= 16 and K = 4096 the weight-stream kernel emits stage-1 candidates (k per workgroup and
- * row) from its epilogue and only the merge stage follows; other shapes run the two entry points
- * above back to back.  Results are identical either way (the candidates are taken from the bf16
- * logits that are stored).  workspace: eagle_lm_head_topk_workspace_bytes(M, N, k). */
-int64_t eagle_lm_head_topk_workspace_bytes(int M, int N, int k);
-int eagle_lm_head_topk_bf16(const void* x, const int64_t* idx0, int64_t ldx, const void* W, void* logits,
-                            int64_t ldl, int M, int N, int K, int k, int64_t* out_idx, void* out_val,
-                            void* workspace, eagle_stream_t stream);
-
 /* Static-tree kernels (Llama2Model.init_tree / tree_mask hooks,
  * eagle/llama2.py:453-458 -- the algorithm itself is the upstream EAGLE-1 one). */
 /* out_ids[b][j] = flat_ids[b][tree_idx[j]]: draft tokens of one expansion step. */

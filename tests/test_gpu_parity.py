@@ -646,26 +646,3 @@ def test_verify_ring_cursor_matches_direct_buffers():
     for a, b in zip(*runs):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
-
-# ------------------------------------------------------------------ fused lm_head + top-k
-@pytest.mark.parametrize("M,V,K,gather", [(4, 32000, 4096, False), (1, 32000, 4096, True), (8, 151936, 4096, True),
-                                          (16, 2000, 4096, False), (5, 100, 4096, False), (3, 1000, 256, False),
-                                          (20, 32000, 4096, True), (7, 40000, 4096, False)])
-def test_lm_head_topk_matches_gemm_then_stable_sort(M, V, K, gather):
-    """eagle_lm_head_topk_bf16 (stage-1 candidates from the GEMM epilogue when M <= 16, K = 4096) must
-    write the same logits as the plain weight-stream GEMM and the top-k of exactly those logits in
-    the oracle's order (value desc, index asc); coarse weights make bf16 ties frequent."""
-    from eagle_amd import ops
-    g = torch.Generator().manual_seed(M * 7 + V + K)
-    rows = M + 5
-    x = (torch.randn(rows, K, generator=g)).to(BF).to(dev())
-    W = ((torch.randn(V, K, generator=g) * 4).round() / 64).to(BF).to(dev())        # few distinct values -> ties
-    idx = torch.randint(0, rows, (M,), generator=g).to(dev()) if gather else None
-    logits, vals, ids = ops.lm_head_topk(x, W, 10, idx0=idx, M=M)
-    ref_logits = ops.linear_skinny(x, W, idx0=idx, M=M)
-    assert torch.equal(logits, ref_logits), "fused kernel must store the same bf16 logits"
-    rv, ri = ot.stable_topk(logits.cpu(), min(10, V))
-    assert torch.equal(ids.cpu()[:, : ri.shape[1]], ri), "top-k ids differ from the stable descending sort"
-    assert torch.equal(vals.cpu()[:, : rv.shape[1]], rv)
-    xs = x[idx] if gather else x[:M]
-    close(logits, xs.float() @ W.float().t(), what="lm_head logits")
