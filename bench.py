@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-micro-batch", type=int, default=2, help="sequences per micro-batch (pages/train_qwen_3.md:19)")
+    ap.add_argument("--train-ga", type=int, default=2, help="gradient accumulation steps (pages/train_qwen_3.md:20)")
     ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--plant", type=float, default=0.8, help="probability that the synthetic verifier agrees with a drafted child")
@@ -266,7 +268,7 @@ def cpu_train_baseline(config: str = "qwen3_8b", L: int = 256, max_seconds: floa
         n += 1
     dt = time.perf_counter() - t0
     return {"value": n * L / dt, "unit": "loss tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} optimizer steps of one 1x{L}-token micro-batch (the GPU leg runs 1x2048), bf16 torch CPU oracle "
+            "sample": f"{n} optimizer steps of one 1x{L}-token micro-batch (the GPU leg runs micro-batches of 2x2048), bf16 torch CPU oracle "
                       "(forward + loss + autograd backward + AdamW)"}
 
 
@@ -349,7 +351,8 @@ def main():
         from eagle_amd.train_bench import train_tokens_per_s
         del drafter, ver, tgt_kv
         torch.cuda.empty_cache()
-        tr = train_tokens_per_s(dev, rank, world, dist, steps=a.train_steps, warmup=a.train_warmup)
+        tr = train_tokens_per_s(dev, rank, world, dist, steps=a.train_steps, warmup=a.train_warmup, ga=a.train_ga,
+                                micro_batch=a.train_micro_batch)
         if rank == 0 and tr is not None:
             if world == 1 and not a.no_cpu_baseline:
                 tr["cpu_baseline"] = cpu_train_baseline()

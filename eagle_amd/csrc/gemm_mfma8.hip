@@ -47,20 +47,42 @@ struct Gemm8Args {
   float* partial;      // [ksplit][M][N] fp32 (split-K only)
 };
 
-// half-tile `h` (0/1) of operand X (rows r0.., clamped to nrows-1) at K tile kt -> lds
-__device__ __forceinline__ void g8_stage(const bf16_t* X, int64_t ld, int nrows, int r0, int h, int kt, bf16_t* lds, int tid) {
+// Operand staging by buffer_load ... lds: the row/chunk part of every lane's source address never
+// changes along K, so it is computed once per thread (32-bit byte offsets from the block's first row,
+// the XOR chunk swizzle and the row clamp folded in) and a K tile only moves the scalar offset --
+// no per-piece address arithmetic in the main loop, and half the address bits of a 64-bit global load.
+struct G8Src {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff[2][2];                 // [half-tile][piece]
+};
+__device__ __forceinline__ G8Src g8_src(const bf16_t* X, int64_t ld, int nrows, int r0, int K, int tid) {
+  G8Src s;
+  const int avail = nrows - r0;                                  // >= 1 (launcher: every tile has a valid first row)
+  const int last = avail < 256 ? avail - 1 : 255;
+  const bf16_t* base = X + (int64_t)r0 * ld;
+  const uint64_t bytes = ((uint64_t)last * (uint64_t)ld + (uint64_t)K) * 2ull;
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes), 0x00020000);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int L = i * G8_THREADS + tid;      // 16-byte slot in the [128][8] image
+      const int row = L >> 3, slot = L & 7;
+      const int chunk = slot ^ (row & 7);
+      int gr = h * 128 + row;
+      gr = gr < last ? gr : last;
+      s.voff[h][i] = (uint32_t)(((uint64_t)gr * (uint64_t)ld + (uint64_t)(chunk * 8)) * 2ull);
+    }
+  return s;
+}
+// half-tile `h` at K tile kt -> lds (wave-uniform LDS base in M0; the hardware adds lane*16)
+__device__ __forceinline__ void g8_stage(const G8Src& s, int h, int kt, bf16_t* lds, int tid) {
   const int wave = tid >> 6;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int L = i * G8_THREADS + tid;        // 16-byte slot in the [128][8] image
-    const int row = L >> 3, slot = L & 7;
-    const int chunk = slot ^ (row & 7);
-    int gr = r0 + h * 128 + row;
-    gr = gr < nrows ? gr : nrows - 1;
-    const bf16_t* g = X + (int64_t)gr * ld + kt * G8_BK + chunk * 8;
-    bf16_t* d = lds + (i * G8_THREADS + wave * 64) * 8;   // wave-uniform base; HW adds lane*16
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+    bf16_t* d = lds + (i * G8_THREADS + wave * 64) * 8;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (__attribute__((address_space(3))) void*)d, 16, s.voff[h][i],
+                                             kt * (G8_BK * 2), 0, 0);
   }
 }
 
@@ -94,8 +116,9 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   const int nk = min(p.kchunk, nk_all - kt0);       // K tiles of this slice (>= 1: launcher)
   auto kt_of = [&](int t) { return (DBG & 8) ? kt0 + (t & 1) : kt0 + (t < nk ? t : nk - 1); };
   auto hbuf = [&](int buf, int which) { return lds + (buf * 4 + which) * G8_HALF; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
-  auto stage_a = [&](int h, int t) { g8_stage(p.A, p.lda, p.M, m0, h, kt_of(t), hbuf(t & 1, h), tid); };
-  auto stage_b = [&](int h, int t) { g8_stage(p.B, p.ldb, p.N, n0, h, kt_of(t), hbuf(t & 1, 2 + h), tid); };
+  const G8Src srcA = g8_src(p.A, p.lda, p.M, m0, p.K, tid), srcB = g8_src(p.B, p.ldb, p.N, n0, p.K, tid);
+  auto stage_a = [&](int h, int t) { g8_stage(srcA, h, kt_of(t), hbuf(t & 1, h), tid); };
+  auto stage_b = [&](int h, int t) { g8_stage(srcB, h, kt_of(t), hbuf(t & 1, 2 + h), tid); };
 
   // prologue: tile 0 complete, B halves of tile 1 in flight
   stage_b(0, 0); stage_b(1, 0); stage_a(0, 0); stage_a(1, 0);
@@ -299,6 +322,7 @@ extern "C" void eagle_debug_set_gemm8_pingpong(int on) { g_g8_pingpong = on; }
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                           const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
                           void* workspace, hipStream_t stream) {
+  if (lda > (1ll << 22) || ldb > (1ll << 22)) return EAGLE_ERR_SHAPE;   // 32-bit byte offsets span 256 rows of a tile
   Gemm8Args a;
   const int nk = K / G8_BK;
   if (ksplit < 1) ksplit = 1;

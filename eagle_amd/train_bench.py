@@ -1,8 +1,10 @@
 """Draft-head training throughput (BASELINE.json configs[2]): Qwen3-8B-dims draft head
 (resources/eagle_config_qwen3_8b.json: D=4096, I=12288, 32 heads, V=151936), fused smooth-L1 + CE
-against a frozen lm_head, sequence 2048, one micro-batch of 1 x 2048 tokens per rank and optimizer
-step, data parallel over the ranks with one bucketed RCCL all-reduce of the flat bf16 gradient
-per step (eagle/train.py:85-131).  Synthetic verifier hidden states / ids, random-init weights.
+against a frozen lm_head, sequence 2048, per rank and optimizer step `ga` micro-batches of
+`micro_batch` x 2048 tokens (bench.py passes the reference's own Qwen3 recipe per GPU: micro-batch 2,
+gradient accumulation 2, pages/train_qwen_3.md:19-20), data parallel over the ranks with one bucketed
+RCCL all-reduce of the flat bf16 gradient per optimizer step, deferred over the accumulation
+micro-batches (eagle/train.py:85-131).  Synthetic verifier hidden states / ids, random-init weights.
 
 Called from bench.py on every rank (collectives inside).  Tokens/s follows eagle/train.py:140-141:
 loss-masked tokens per step / step wall time, summed over ranks.
@@ -69,7 +71,7 @@ def flops_per_token(cfg, L: int) -> float:
 
 
 def train_tokens_per_s(dev, rank: int, world: int, dist, steps: int = 6, warmup: int = 2, L: int = 2048,
-                       config: str = "qwen3_8b", ga: int = 1) -> Optional[dict]:
+                       config: str = "qwen3_8b", ga: int = 1, micro_batch: int = 1) -> Optional[dict]:
     from .config import DraftConfig, LLAMA2_7B_DRAFT, QWEN3_8B_DRAFT
     from .llama2 import Llama2Model
     from .train import EagleTrainer
@@ -90,15 +92,15 @@ def train_tokens_per_s(dev, rank: int, world: int, dist, steps: int = 6, warmup:
     tr = EagleTrainer(model, lm_head, lr=2e-4, betas=(0.9, 0.95), grad_clip=0.5, num_warmup_steps=world * 10,
                       num_training_steps=world * 1000, mode="dp", group=group, world_size=world)
     gd = torch.Generator(device=dev).manual_seed(1000 + rank)  # different data per rank
-    D = cfg.hidden_size
+    D, MB = cfg.hidden_size, micro_batch
 
     def batch():
-        hid = torch.randn((1, L, D), generator=gd, device=dev, dtype=torch.float32).to(BF16)
-        noise = ((torch.rand((1, L, D), generator=gd, device=dev) - 0.5) * 0.2).to(BF16)
-        ids = torch.randint(0, cfg.vocab_size, (1, L), generator=gd, device=dev)
+        hid = torch.randn((MB, L, D), generator=gd, device=dev, dtype=torch.float32).to(BF16)
+        noise = ((torch.rand((MB, L, D), generator=gd, device=dev) - 0.5) * 0.2).to(BF16)
+        ids = torch.randint(0, cfg.vocab_size, (MB, L), generator=gd, device=dev)
         from . import ops
         h, t, i = ops.make_eagle_input(hid, ids, noise)
-        return {"hidden_states": h, "target": t, "input_ids": i, "loss_mask": torch.ones((1, L), dtype=torch.int64, device=dev)}
+        return {"hidden_states": h, "target": t, "input_ids": i, "loss_mask": torch.ones((MB, L), dtype=torch.int64, device=dev)}
 
     pool = [[batch() for _ in range(ga)] for _ in range(2)]
 
@@ -121,12 +123,12 @@ def train_tokens_per_s(dev, rank: int, world: int, dist, steps: int = 6, warmup:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     sums = out["sums"].cpu()
-    toks = world * ga * L * steps
+    toks = world * ga * MB * L * steps
     fpt = flops_per_token(cfg, L)
     tf = toks * fpt / dt / 1e12
     res = {"value": toks / dt, "unit": "loss tokens/s (whole job)", "ms_per_step": dt / steps * 1e3, "n_gpus": world,
            "config": {"workload": f"BASELINE configs[2]: {config} dims draft head training, fused smooth-L1+CE, seq {L}, "
-                                  f"micro-batch 1x{L} per GPU, GA {ga}, DP={world} (RCCL all-reduce of the flat bf16 gradient)"},
+                                  f"micro-batch {MB}x{L} per GPU, GA {ga}, DP={world} (RCCL all-reduce of the flat bf16 gradient)"},
            "dtype": "bf16", "steps": steps, "warmup": warmup,
            "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / world / MFMA_PEAK_TFLOPS,
                         "flops_per_token": fpt, "note": "whole training step (all kernels + all-reduce) per GPU, algorithmic flops"},

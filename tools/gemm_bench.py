@@ -3,6 +3,7 @@ import sys, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from eagle_amd import ops
 dev = torch.device('cuda:0')
+MT = int(sys.argv[1]) if len(sys.argv) > 1 else 2048          # tokens per micro-batch
 shapes = [(2048, 4096, 8192, 'fc'), (2048, 12288, 4096, 'qkv'), (2048, 4096, 4096, 'o'), (2048, 24576, 4096, 'gate|up qwen'),
           (2048, 4096, 12288, 'down qwen'), (2048, 151936, 4096, 'lm_head qwen'), (2048, 4096, 151936, 'lm dgrad'),
           (4096, 12288, 2048, 'wgrad-like'), (8192, 4096, 4096, 'o 8k tokens')]
@@ -12,6 +13,8 @@ setm = _hip.lib().eagle_debug_set_gemm8
 setm.argtypes, setm.restype = [ctypes.c_int], None
 setpp = _hip.lib().eagle_debug_set_gemm8_pingpong
 setpp.argtypes, setpp.restype = [ctypes.c_int], None
+shapes = [(MT if M == 2048 else M, N, MT if K == 2048 else K, n) for M, N, K, n in shapes[:8]]
+shapes += [(4096, 4096, MT, 'wgrad o'), (12288, 4096, MT, 'wgrad qkv'), (4096, 8192, MT, 'wgrad fc'), (24576, 4096, MT, 'wgrad gate|up'), (4096, 12288, MT, 'wgrad down')]
 for M, N, K, name in shapes:
     A = torch.randn(M, K, device=dev).to(torch.bfloat16); B = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
