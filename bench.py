@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the batch-32 configs[3] leg")
     ap.add_argument("--train-micro-batch", type=int, default=2, help="sequences per micro-batch (pages/train_qwen_3.md:19)")
     ap.add_argument("--train-ga", type=int, default=2, help="gradient accumulation steps (pages/train_qwen_3.md:20)")
     ap.add_argument("--train-steps", type=int, default=6)
@@ -241,6 +242,66 @@ def cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, expand, max_
                       f"bf16 torch CPU oracle, batch 1, ctx~{hidden.shape[1]}"}
 
 
+def batched_leg(dev, B=32, cycles=10, warm=3, plant_prob=0.8, seed=11):
+    """BASELINE configs[3]: batch of B requests with ShareGPT-like ragged prompt lengths (log-normal,
+    median ~300 tokens, clipped to [16, 1500]), Qwen3-8B draft dims (V = 151936), static tree, greedy
+    verify; one replica.  Same protocol as the headline leg: an untimed recording pass plants agreement
+    in a ring of synthetic verifier outputs, the timed pass replays it (eager launches: the batched
+    path is not launch-bound) and must end in the same state."""
+    from eagle_amd.speculative import EagleDrafter
+    cfg, model, lm_head = make_model("qwen3_8b", dev, seed=1)
+    drafter = EagleDrafter(model, lm_head, batch=B, max_ctx=2048)
+    tb = drafter.tb
+    g = torch.Generator().manual_seed(seed)
+    lens = [int(min(1500, max(16, x))) for x in torch.exp(torch.randn(B, generator=g) * 0.8 + 5.7).tolist()]
+    gd = torch.Generator(device=dev).manual_seed(seed)
+    hid = [torch.randn((n, cfg.hidden_size), generator=gd, device=dev, dtype=torch.float32).to(torch.bfloat16) for n in lens]
+    tok = [torch.randint(0, cfg.vocab_size, (n + 1,), generator=gd, device=dev) for n in lens]
+    n_cyc = warm + cycles
+    logits = torch.randn((n_cyc, B, tb.n_nodes, cfg.vocab_size), generator=gd, device=dev, dtype=torch.bfloat16)
+    hidden = torch.randn((n_cyc, B, tb.n_nodes, cfg.hidden_size), generator=gd, device=dev, dtype=torch.bfloat16)
+    tgt_kv = torch.zeros((72, B, 8, 2048 + 64, 128), dtype=torch.bfloat16, device=dev)     # 36-layer GQA verifier cache
+    kids_of = {}
+    for i in range(1, tb.n_nodes):
+        kids_of.setdefault(tb.parent[i], []).append(i)
+
+    def run(record):
+        drafter.prefill_ragged(hid, tok)
+        root = torch.stack([t[-1] for t in tok])
+        prev = torch.tensor(lens, dtype=torch.int32, device=dev)
+        t0 = None
+        for c in range(n_cyc):
+            if record:
+                tree_tok = torch.cat([root[:, None], drafter.flat_ids.reshape(B, -1)], dim=1)[:, tb.tree_indices].cpu()
+                for b in range(B):
+                    node = 0
+                    while node in kids_of and float(torch.rand(1, generator=g)) < plant_prob:
+                        kid = kids_of[node][int(torch.randint(0, len(kids_of[node]), (1,), generator=g))]
+                        logits[c, b, node, int(tree_tok[b, kid])] = 60.0
+                        node = kid
+            if c == warm:
+                torch.cuda.synchronize()
+                len0, t0 = prev.clone(), time.perf_counter()
+            drafter.verify(root, logits[c], prev)
+            acc_h = drafter.compact(prev, tgt_kv, hidden[c], kv_inner=8, root_io=root, update_prev_len=True)
+            drafter.draft(acc_h, drafter.next_ids)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        drafter.check_errors()
+        return (prev.cpu().tolist(), root.cpu().tolist()), int((prev - len0).sum()), dt
+
+    with torch.no_grad():
+        rec, _, _ = run(True)
+        fin, accepted, dt = run(False)
+    if fin != rec:
+        raise SystemExit("batched leg: timed replay diverged from the recorded generation")
+    n_fw = 1 + len(tb.steps)
+    return {"value": B * n_fw * cycles / dt, "unit": "draft-tree steps/s (all requests)", "ms_per_cycle": dt / cycles * 1e3,
+            "cycles": cycles, "mean_accept_len": accepted / (B * cycles),
+            "config": {"workload": f"BASELINE configs[3]: batch {B}, ragged prompts (log-normal, median ~300, {min(lens)}..{max(lens)} tokens), "
+                                   "qwen3_8b draft dims, static tree depth 5 / top-k 10, greedy verify, one replica, eager launches"}}
+
+
 def cpu_train_baseline(config: str = "qwen3_8b", L: int = 256, max_seconds: float = 25.0) -> dict:
     """CPU oracle (oracle/train_step.py, torch autograd, 'port') on a BOUNDED sample of the same
     workload: one micro-batch of 1 x L tokens (L = 256 instead of 2048: a full-length step takes
@@ -274,17 +335,30 @@ def cpu_train_baseline(config: str = "qwen3_8b", L: int = 256, max_seconds: floa
 
 def main():
     a = parse()
+    if os.environ.get("EAGLE_BENCH_TRACE"):          # rehearsal aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["EAGLE_BENCH_TRACE"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    # EAGLE_BENCH_BACKEND=gloo: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (the ranks
+    # then share the visible devices; RCCL refuses two ranks on one GPU).  Default: RCCL, one rank per GPU.
+    backend = os.environ.get("EAGLE_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and world > n_dev:
+        raise SystemExit(f"{world} ranks need {world} GPUs (found {n_dev}); one process per GPU over RCCL")
+    local = local % max(1, n_dev)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def sync():
         torch.cuda.synchronize()
@@ -347,10 +421,13 @@ def main():
             out["roofline"] = roofline_lm_head(drafter, ver, tgt_kv, root, plen)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, a.expand)
+    del drafter, ver, tgt_kv, model, lm_head
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not a.no_batched:
+        out["batched"] = batched_leg(dev)
+        torch.cuda.empty_cache()
     if not a.no_train:
         from eagle_amd.train_bench import train_tokens_per_s
-        del drafter, ver, tgt_kv
-        torch.cuda.empty_cache()
         tr = train_tokens_per_s(dev, rank, world, dist, steps=a.train_steps, warmup=a.train_warmup, ga=a.train_ga,
                                 micro_batch=a.train_micro_batch)
         if rank == 0 and tr is not None:

@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libeagle_hip.so")
+LIB_PATH = os.environ.get("EAGLE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libeagle_hip.so")
 
 _ERR = {1: "EAGLE_ERR_SHAPE (operand shapes outside what the kernel assumes)",
         2: "EAGLE_ERR_LAUNCH (HIP launch failed)", 3: "EAGLE_ERR_ARG (null pointer / bad enum)"}

@@ -31,6 +31,10 @@
 #define G8_BN 256
 #define G8_BK 64
 #define G8_THREADS 512
+#ifndef G8_PRIO_M
+#define G8_PRIO_M 1
+#define G8_PRIO_R 0
+#endif
 #define G8_HALF (128 * G8_BK)           // elements per half-tile (16 KB)
 
 struct Gemm8Args {
@@ -149,12 +153,12 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   };
 
 #define G8_MFMA(MH, NH, BF)                                                                           \
-  __builtin_amdgcn_s_setprio(1);                                                                      \
+  __builtin_amdgcn_s_setprio(G8_PRIO_M);                                                                   \
   _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                       \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
     acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][s], af[i][s], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
-  __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(G8_PRIO_R);
 
   if (PINGPONG) {
     // Ping-pong schedule: the two waves of a SIMD (wr = 0 / wr = 1 share it) run the same program one

@@ -169,6 +169,17 @@ class Llama2Model(nn.Module):
             self._packed[("mlp", li)] = hit
         return hit[1], hit[2]
 
+    def _stacked_mlp(self, li: int):
+        """gate|up stacked into one [2I, D] weight (wide-batch path); rebuilt when a source changes."""
+        m = self.layers[li].mlp
+        srcs = (m.gate_proj.weight, m.up_proj.weight)
+        key = tuple((w.data_ptr(), w._version) for w in srcs)
+        hit = self._packed.get(("gu", li))
+        if hit is None or hit[0] != key:
+            hit = (key, torch.cat([w.detach() for w in srcs], dim=0).contiguous())
+            self._packed[("gu", li)] = hit
+        return hit[1]
+
     def _cache_for(self, li: int, B: int, need: int, device, past) -> _LayerCache:
         H, HK, hd = self._dims()
         while len(self._caches) <= li:
@@ -240,8 +251,16 @@ class Llama2Model(nn.Module):
             x = ops.linear_skinny(attn, a.o_proj.weight, res=x)
             # post_attention_layernorm fused into the gate/up projection: the norm weight is folded
             # into the weight columns, the row scale rsqrt(mean(x^2)+eps) is computed in-kernel
-            wg, wu = self._folded_mlp(li)
-            act = ops.linear_skinny(x, wg, W2=wu, norm_eps=layer.post_attention_layernorm.variance_epsilon)
+            if M > 64 and x.shape[1] % 64 == 0:
+                # wide batches (BASELINE configs[3], batch 32): one pass of gate|up on the LDS-tiled MFMA GEMM
+                # instead of one weight-stream pass per 32 rows
+                n = ops.rmsnorm(x, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
+                wgu = self._stacked_mlp(li)
+                tiles = ((M + 255) // 256) * ((wgu.shape[0] + 255) // 256)
+                act = ops.silu_mul(ops.gemm_nt(n, wgu, ksplit=2 if tiles <= 128 else 1))
+            else:
+                wg, wu = self._folded_mlp(li)
+                act = ops.linear_skinny(x, wg, W2=wu, norm_eps=layer.post_attention_layernorm.variance_epsilon)
             x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x)
         return x
 

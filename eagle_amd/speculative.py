@@ -97,7 +97,10 @@ class EagleDrafter:
     # -------------------------------------------------------------- draft side
     def _head_topk(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int, row0: int, n: int):
         """top-k(lm_head(x[idx])) -> flat rows [row0, row0+n) of every request."""
-        logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
+        if idx is None and rows > 64 and self.D % 64 == 0:
+            logits = ops.gemm_nt(x, self.lm_head)            # wide batches: one weight pass on the MFMA GEMM
+        else:
+            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
         if self.B == 1:
             ops.topk(logits, self.k, out_idx=self.flat_ids[0, row0:row0 + n], out_val=self.flat_vals[0, row0:row0 + n],
                      workspace=self._ws)

@@ -164,3 +164,62 @@ def test_batch32_real_dims_cycle_is_self_consistent():
         assert batched.stable_len.tolist() == [c + e[1] + 1 for c, e in zip(ctxs, expect)]
         assert int(ids2.min()) >= 0 and int(ids2.max()) < cfg.vocab_size
         batched.check_errors()
+
+
+def test_chain_tree_is_the_reference_benchmark_setting():
+    """benchmark/README.md:52-54 runs SGLang with --steps 4 --k 1 --draft 4: one candidate per step, a
+    chain.  The static-tree machinery covers it with the chain as its tree and top-k = 1; the cycle
+    must match the oracle loop bit for bit (ids, acceptance, compaction)."""
+    from eagle_amd import ops
+    from eagle_amd.speculative import EagleDrafter
+    d = dev()
+    chain = [[0], [0, 0], [0, 0, 0], [0, 0, 0, 0]]
+    dims = dm.DraftDims(hidden=256, inter=512, heads=2, kv_heads=2, vocab=2000)
+    w = dm.init_weights(dims, seed=9, std=0.08)
+    g = torch.Generator().manual_seed(12)
+    lm_head = (torch.randn(dims.vocab, dims.hidden, generator=g) * 0.3).to(BF).to(d)
+    m_api, m_dev = _model(dims, w), _model(dims, w)
+    tb = ot.generate_tree_buffers(paths=chain, topk=1)
+    assert tb.n_nodes == 5 and tb.retrieve_indices.tolist() == [[0, 1, 2, 3, 4]]
+    drafter = EagleDrafter(m_dev, lm_head, tree=chain, topk=1, batch=1, max_ctx=128)
+
+    def draft_fn(h, ids, past_key_values=None, position_ids=None, tree_mask=None, use_cache=True):
+        m_api.tree_mask = None if tree_mask is None else tree_mask.to(d)
+        pk = None if past_key_values is None else tuple((k.to(d), v.to(d)) for k, v in past_key_values)
+        with torch.no_grad():
+            o, kv = m_api(h.to(d), ids.to(d), past_key_values=pk,
+                          position_ids=None if position_ids is None else position_ids.to(d), use_cache=True)
+        return o.cpu(), tuple((k.cpu().clone(), v.cpu().clone()) for k, v in kv)
+
+    def head_fn(h):
+        return ops.linear_skinny(h.to(d).contiguous(), lm_head).cpu()
+
+    ctx = 17
+    tokens = torch.randint(0, dims.vocab, (1, ctx + 1), generator=g)
+    hidden = torch.randn(1, ctx, dims.hidden, generator=g).to(BF)
+    with torch.no_grad():
+        ids_o, vals_o, stable, _ = ot.topk_generate(draft_fn, None, tb, hidden, tokens, None, head_fn=head_fn)
+        ids_g, vals_g = drafter.prefill(hidden.to(d), tokens.to(d))
+        assert torch.equal(ids_g[0].cpu(), ids_o) and torch.equal(vals_g[0].cpu(), vals_o)
+        prev_len = ctx
+        for cycle, n_agree in enumerate([4, 0, 2]):
+            tgt_logits = (torch.randn(tb.n_nodes, dims.vocab, generator=g) * 2).to(BF)
+            tgt_hidden = torch.randn(1, tb.n_nodes, dims.hidden, generator=g).to(BF)
+            tree_tok, cart = ot.tree_candidates(int(tokens[0, -1]), ids_o, tb)
+            for node in range(n_agree):
+                tgt_logits[node, int(tree_tok[node + 1])] = 50.0
+            best, alen, nxt, _ = ot.greedy_accept(cart, ot.first_argmax(tgt_logits), tb)
+            assert alen >= n_agree
+            prev_dev = torch.tensor([prev_len], dtype=torch.int32, device=d)
+            res = drafter.verify(tokens[:, -1].to(d), tgt_logits.to(d)[None], prev_dev)
+            assert res[0].tolist() == [best, alen, nxt, prev_len + alen + 1]
+            acc_h_g = drafter.compact(prev_dev, None, tgt_hidden.to(d))
+            _, acc_h = ot.compact([], tgt_hidden, tb, best, alen, prev_len)
+            assert torch.equal(acc_h_g[0, : alen + 1].cpu(), acc_h[0])
+            path_tokens = [int(cart[best, j]) for j in range(1, alen + 1)] + [nxt]
+            tokens = torch.cat([tokens, torch.tensor([path_tokens])], dim=1)
+            ids_o, vals_o, stable, _ = ot.topk_generate(draft_fn, None, tb, acc_h, tokens, stable, head_fn=head_fn)
+            ids_g, vals_g = drafter.draft(acc_h_g, drafter.next_ids)
+            assert torch.equal(ids_g[0].cpu(), ids_o), f"cycle {cycle}: chain ids differ"
+            prev_len += alen + 1
+        drafter.check_errors()
