@@ -302,6 +302,76 @@ def batched_leg(dev, B=32, cycles=10, warm=3, plant_prob=0.8, seed=11):
                                    "qwen3_8b draft dims, static tree depth 5 / top-k 10, greedy verify, one replica, eager launches"}}
 
 
+def dynamic_leg(dev, steps=5, topk=8, draft=32, ctx=300, cycles=60, warm=6, plant_prob=0.8, seed=21):
+    """the dynamic (EAGLE-2 / SGLang) tree on the headline model -- Llama-2-7B draft
+    dims, `steps` draft forwards of `topk` rows per cycle, `draft` verified nodes, greedy verify, batch 1,
+    one HIP graph per cycle.  Same record / replay protocol as the headline leg."""
+    from eagle_amd.dynamic import EagleDynamicDrafter
+    cfg, model, lm_head = make_model("llama2_7b", dev, seed=0)
+    dr = EagleDynamicDrafter(model, lm_head, steps=steps, topk=topk, num_draft_tokens=draft, max_ctx=2048)
+    n_cyc = warm + cycles
+    dr.kv_bound = min(dr.cap, (ctx + (n_cyc + 1) * dr.W + dr.n_tree + 63) // 64 * 64)
+    gd = torch.Generator(device=dev).manual_seed(seed)
+    g = torch.Generator().manual_seed(seed)
+    hid = torch.randn((1, ctx, cfg.hidden_size), generator=gd, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    tok = torch.randint(0, cfg.vocab_size, (1, ctx + 1), generator=gd, device=dev)
+    logits = torch.randn((n_cyc, draft, cfg.vocab_size), generator=gd, device=dev, dtype=torch.bfloat16)
+    hidden = torch.randn((n_cyc, 1, draft, cfg.hidden_size), generator=gd, device=dev, dtype=torch.bfloat16)
+    tgt_kv = torch.zeros((64, 1, 32, 2048 + 64, 128), dtype=torch.bfloat16, device=dev)
+
+    def run(record):
+        dr.prefill(hid, tok)
+        root = tok[0, -1:].clone()
+        prev = torch.full((1,), ctx, dtype=torch.int32, device=dev)
+        cursor = torch.zeros(2, dtype=torch.int64, device=dev)
+
+        def one_cycle():
+            dr.verify(logits, prev, cursor=cursor)
+            acc_h = dr.compact(prev, tgt_kv, hidden, kv_inner=32, root_io=root, update_prev_len=True, cursor=cursor)
+            dr.draft(acc_h, dr.next_ids)
+
+        graph, t0, len0 = None, None, None
+        for c in range(n_cyc):
+            if record:
+                t_tok, t_par = dr.tree_tok.cpu().tolist(), dr.tree_parent.cpu().tolist()
+                node = 0
+                while float(torch.rand(1, generator=g)) < plant_prob:
+                    kids = [n for n in range(1, draft) if t_par[n] == node]
+                    if not kids:
+                        break
+                    node = kids[int(torch.randint(0, len(kids), (1,), generator=g))]
+                    logits[c, t_par[node], t_tok[node]] = 60.0
+            if c == warm:
+                torch.cuda.synchronize()
+                len0, t0 = prev.clone(), time.perf_counter()
+            if record:
+                one_cycle()
+            elif graph is None and c >= 2:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    one_cycle()
+                graph.replay()
+            elif graph is not None:
+                graph.replay()
+            else:
+                one_cycle()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        dr.check_errors()
+        return (prev.cpu().tolist(), root.cpu().tolist()), int((prev - len0).sum()), dt
+
+    with torch.no_grad():
+        rec, _, _ = run(True)
+        fin, accepted, dt = run(False)
+    if fin != rec:
+        raise SystemExit("dynamic-tree leg: timed replay diverged from the recorded generation")
+    return {"value": steps * cycles / dt, "unit": "draft-tree steps/s", "ms_per_cycle": dt / cycles * 1e3, "cycles": cycles,
+            "mean_accept_len": accepted / cycles,
+            "config": {"workload": f"dynamic tree (SGLang flags --steps {steps} --k {topk} --draft {draft}), llama2_7b draft dims, "
+                                   f"greedy verify, batch 1, ctx {ctx}, HIP graph per cycle"}}
+
+
 def cpu_train_baseline(config: str = "qwen3_8b", L: int = 256, max_seconds: float = 25.0) -> dict:
     """CPU oracle (oracle/train_step.py, torch autograd, 'port') on a BOUNDED sample of the same
     workload: one micro-batch of 1 x L tokens (L = 256 instead of 2048: a full-length step takes
@@ -425,6 +495,8 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not a.no_batched:
         out["batched"] = batched_leg(dev)
+        torch.cuda.empty_cache()
+        out["dynamic_tree"] = dynamic_leg(dev)
         torch.cuda.empty_cache()
     if not a.no_train:
         from eagle_amd.train_bench import train_tokens_per_s

@@ -49,6 +49,10 @@ SIGNATURES = {
     "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, P, P, P, P, I, P, P, P, I, P]),
     "eagle_kv_compact_bf16": (I, [P, L, L, I, I, I, P, I, P, P, I, P, P]),
     "eagle_gather_accepted_bf16": (I, [P, I, I, P, I, P, P, P, P, P, I, P]),
+    "eagle_row_lse_bf16": (I, [P, L, I, I, P, P]),
+    "eagle_dyn_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "eagle_dyn_finalize": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P]),
+    "eagle_dyn_accept": (I, [I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "eagle_ce_stat_bytes": (I, []),
     "eagle_ce_partial_bf16": (I, [P, P, L, I, I, I, P, P, I, P, P]),
     "eagle_ce_combine": (I, [P, I, I, P, P, P, P, P, P]),

@@ -426,3 +426,35 @@ def rope_tables(head_dim: int, n_pos: int, base: float = 10000.0, device=None):
     fr = torch.outer(t, inv_freq)
     ang = torch.cat((fr, fr), dim=-1)
     return ang.cos().to(BF16).to(device), ang.sin().to(BF16).to(device)
+
+
+# ------------------------------------------------------------------ dynamic tree (batch 1)
+def row_lse(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 log-sum-exp of every row of bf16 logits [rows, V]."""
+    _chk(logits, "logits")
+    rows, V = logits.shape
+    if logits.stride(1) != 1:
+        raise ValueError("row_lse: rows must be contiguous")
+    if out is None:
+        out = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    call("eagle_row_lse_bf16", ptr(logits), logits.stride(0), rows, V, ptr(out), stream())
+    return out
+
+
+def dyn_step(step: int, k: int, last: bool, vals, ids, lse, fscore_in, fpool_in, mask_in, root_row, pool_tok, pool_score,
+             pool_parent, ftok, fscore_out, fpool_out, parent_row, mask_out) -> None:
+    call("eagle_dyn_step", step, k, int(last), ptr(vals), ptr(ids), ptr(lse), ptr(fscore_in), ptr(fpool_in), ptr(mask_in),
+         ptr(root_row), ptr(pool_tok), ptr(pool_score), ptr(pool_parent), ptr(ftok), ptr(fscore_out), ptr(fpool_out),
+         ptr(parent_row), ptr(mask_out), stream())
+
+
+def dyn_finalize(k: int, S: int, T: int, pool_tok, pool_score, pool_parent, root_token, tree_tok, tree_parent, tree_pos,
+                 tree_mask, sel) -> None:
+    call("eagle_dyn_finalize", k, S, T, ptr(pool_tok), ptr(pool_score), ptr(pool_parent), ptr(root_token), ptr(tree_tok),
+         ptr(tree_parent), ptr(tree_pos), ptr(tree_mask), ptr(sel), stream())
+
+
+def dyn_accept(T: int, W: int, tree_tok, tree_parent, target_argmax, prev_len, path, result, next_ids=None, n_acc=None,
+               last_idx=None, len_cur=None, len_nxt=None, cursor=None) -> None:
+    call("eagle_dyn_accept", T, W, ptr(tree_tok), ptr(tree_parent), ptr(target_argmax), ptr(prev_len), ptr(path), ptr(result),
+         ptr(next_ids), ptr(n_acc), ptr(last_idx), ptr(len_cur), ptr(len_nxt), ptr(cursor), stream())

@@ -173,6 +173,40 @@ int eagle_gather_accepted_bf16(const void* src, int n_nodes, int D, const int64_
                                const int64_t* result, void* out, int64_t* root_io, int32_t* prev_len_io,
                                const int64_t* src_block, int B, eagle_stream_t stream);
 
+/* Dynamic draft tree (EAGLE-2 as SGLang serves it; benchmark/benchmark.py:48-56 passes
+ * speculative_num_steps / speculative_eagle_topk / speculative_num_draft_tokens to sglang.Engine --
+ * the algorithm itself is not in the reference; spec frozen in DESIGN.md 6b, oracle/dyn_tree.py).
+ * Batch 1.  k = candidates per node (<= 16), S = steps, T = verified nodes incl. the root (<= 64),
+ * pool = k + (S-1) k^2 candidates (<= 1024) in production order; score = product of softmax
+ * probabilities along the path; order = score descending, pool index ascending. */
+/* lse[r] = log sum_v exp(logits[r][v]) (fp32): the softmax normaliser of the draft head's top-k. */
+int eagle_row_lse_bf16(const void* logits, int64_t ld, int rows, int V, float* lse, eagle_stream_t stream);
+/* One expansion step: vals/ids [R,k] = top-k of the R = (step ? k : 1) rows just computed, lse [R].
+ * Appends the R*k candidates to the pool (token, score, parent pool index) and, unless `last`, makes
+ * the k best the next frontier: ftok [k], fscore_out [k], fpool_out [k], parent_row [k] (row of the
+ * previous forward whose hidden state each takes; step 0: *root_row) and mask_out [k, (step+1) k] =
+ * parent's row of mask_in [k, step k] | own column (select_top_k_tokens of SGLang's EAGLE worker). */
+int eagle_dyn_step(int step, int k, int last, const void* vals, const int64_t* ids, const float* lse,
+                   const float* fscore_in, const int32_t* fpool_in, const uint8_t* mask_in,
+                   const int64_t* root_row, int64_t* pool_tok, float* pool_score, int32_t* pool_parent,
+                   int64_t* ftok, float* fscore_out, int32_t* fpool_out, int64_t* parent_row,
+                   uint8_t* mask_out, eagle_stream_t stream);
+/* The T-1 best pool entries, in pool order, become tree nodes 1..T-1 (organize_draft_results):
+ * tree_tok [T] (node 0 = *root_token), tree_parent [T] int32 (root -1), tree_pos [T] (depth),
+ * tree_mask [T,T] uint8 (self, root, ancestors), sel [T-1] (pool index of node n+1). */
+int eagle_dyn_finalize(int k, int S, int T, const int64_t* pool_tok, const float* pool_score,
+                       const int32_t* pool_parent, const int64_t* root_token, int64_t* tree_tok,
+                       int32_t* tree_parent, int64_t* tree_pos, uint8_t* tree_mask, int32_t* sel,
+                       eagle_stream_t stream);
+/* Greedy acceptance by walking the tree along target_argmax [T]; path [W] (node ids, -1 padded) doubles
+ * as the one-row `retrieve` table of eagle_kv_compact_bf16 / eagle_gather_accepted_bf16 with
+ * result = {0, accept_length, next_token, *prev_len + accept_length + 1}; next_ids / n_acc / last_idx /
+ * len_cur / len_nxt / cursor as eagle_greedy_accept. */
+int eagle_dyn_accept(int T, int W, const int64_t* tree_tok, const int32_t* tree_parent,
+                     const int64_t* target_argmax, const int32_t* prev_len, int64_t* path, int64_t* result,
+                     int64_t* next_ids, int32_t* n_acc, int64_t* last_idx, int32_t* len_cur, int32_t* len_nxt,
+                     int64_t* cursor, eagle_stream_t stream);
+
 /* Fused soft-label CE + smooth-L1 + agreement at the logits level.
  * Replaces eagle/train.py:108-123 (== eagle/train_tp.py:90-105).
  * ce_partial: one vocab shard [N, V] (columns v0..v0+V of the full vocabulary) -> stats [N]
