@@ -134,7 +134,8 @@ def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, pla
             if g is None and c >= 2:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # thread_local: a process group's watchdog thread may touch the runtime during the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     one_cycle()          # capture does not execute: replay below runs this cycle
                 g.replay()
             elif g is not None:
@@ -349,7 +350,7 @@ def dynamic_leg(dev, steps=5, topk=8, draft=32, ctx=300, cycles=60, warm=6, plan
             elif graph is None and c >= 2:
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     one_cycle()
                 graph.replay()
             elif graph is not None:
