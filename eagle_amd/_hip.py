@@ -30,6 +30,7 @@ class HipKernelError(RuntimeError):
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, I, L, F, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
+    "eagle_skinny_resident_weights": (I, [P, I]),
     "eagle_gemm_nt_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, P]),
     "eagle_gemm_nt_splitk_workspace_bytes": (L, [I, I, I]),
     "eagle_gemm_nt_splitk_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, P, P]),

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
 // ---------------------------------------------------------------------------------------------
 template <int RT> struct SkStage { bf16x8 a[4][RT]; bf16x8 b[4]; };
 
-template <int RT, int EPI>
+template <int RT, int EPI, bool NT>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(SkinnyArgs p, int rows_per_block, int n_iter) {
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;   // distinct 16-row groups per tile-step
   constexpr int RPS = RTW * 16;                               // output rows per tile-step
@@ -271,7 +271,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
       const bf16_t* base = (EPI == EPI_SILU_MUL && (t & 1)) ? p.W2 : p.W;
       const bf16_t* wp = base + (int64_t)n * p.K + 8 * g + kb;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) st.a[s][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * 32));
+      for (int s = 0; s < 4; ++s)
+        st.a[s][t] = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * 32)) : *reinterpret_cast<const bf16x8*>(wp + s * 32);
     }
   };
   auto load_x = [&](SkStage<RT>& st, int it) {
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
 // for all of the block's rows (no per-tile-step re-read of x through L2: at 8 tokens that re-read
 // is half as many bytes again as the weight stream), the RMSNorm row statistics are computed once,
 // and the super-step loop is fully unrolled: stage parity, x fragment and refill target are static.
-template <int RT, int EPI, int NI>
+template <int RT, int EPI, int NI, bool NT>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
   static_assert((NI & 1) == 0, "two register stages alternate");
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;
@@ -456,7 +457,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
       const bf16_t* base = (EPI == EPI_SILU_MUL && (t & 1)) ? p.W2 : p.W;
       const bf16_t* wp = base + (int64_t)n * p.K + 8 * g + kb;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) st[s][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * 32));
+      for (int s = 0; s < 4; ++s)
+        st[s][t] = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * 32)) : *reinterpret_cast<const bf16x8*>(wp + s * 32);
     }
   };
   load_w(a[0], 0, 0);
@@ -591,6 +593,27 @@ static int sk_num_cus() {
   return n;
 }
 
+// Cache policy of the weight stream.  A draft forward streams more weight bytes (734 MB, Llama-2-7B dims)
+// than the 256 MB Infinity Cache holds, five times per cycle: with one policy for all of them nothing
+// survives from one forward to the next.  The host names the matrices that should stay resident
+// (eagle_skinny_resident_weights: the smallest ones, up to ~3/4 of the cache); those are read with the
+// default policy, every other weight with non-temporal loads so that it does not displace them.
+#define SK_MAX_RESIDENT 16
+static const void* g_sk_resident[SK_MAX_RESIDENT];
+static int g_sk_n_resident = 0;
+extern "C" int eagle_skinny_resident_weights(const void* const* weights, int n) {
+  if (n < 0 || n > SK_MAX_RESIDENT || (n > 0 && !weights)) return EAGLE_ERR_ARG;
+  for (int i = 0; i < n; ++i) g_sk_resident[i] = weights[i];
+  g_sk_n_resident = n;
+  return EAGLE_OK;
+}
+static bool sk_stream_nt(const SkinnyArgs& a, int epi) {
+  (void)epi;
+  for (int i = 0; i < g_sk_n_resident; ++i)
+    if (g_sk_resident[i] == (const void*)a.W) return false;
+  return true;
+}
+
 template <int RT, int EPI>
 static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
   int grid = sk_num_cus();                             // ~160 VGPRs: one 8-wave block per CU
@@ -598,7 +621,8 @@ static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
   if (R < 16) R = 16;
   R = (R + 3) & ~3;
   grid = (a.N + R - 1) / R;
-  hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  if (sk_stream_nt(a, EPI)) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
   return eagle_check_launch();
 }
 
@@ -607,7 +631,7 @@ static int launch_skinny_stream(const SkinnyArgs& a, hipStream_t st) {
   constexpr int RPS = ((EPI == EPI_SILU_MUL) ? RT / 2 : RT) * 16;
   static int occ = 0;                                  // resident 512-thread blocks per CU for this instantiation
   if (!occ) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_skinny_stream_kernel<RT, EPI>, SK_WAVES * 64, 0) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_skinny_stream_kernel<RT, EPI, true>, SK_WAVES * 64, 0) != hipSuccess || occ < 1) occ = 1;
   }
   int grid = sk_num_cus() * (occ < g_sk_blocks_per_cu ? occ : g_sk_blocks_per_cu);
   int R = (a.N + grid - 1) / grid;
@@ -617,7 +641,8 @@ static int launch_skinny_stream(const SkinnyArgs& a, hipStream_t st) {
   const int nfull = (a.K + 127) >> 7;
   const int n_iter = (nfull + SK_WAVES - 1) / SK_WAVES;
   (void)RPS;
-  hipLaunchKernelGGL((gemm_skinny_stream_kernel<RT, EPI>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R, n_iter);
+  if (sk_stream_nt(a, EPI)) hipLaunchKernelGGL((gemm_skinny_stream_kernel<RT, EPI, true>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R, n_iter);
+  else hipLaunchKernelGGL((gemm_skinny_stream_kernel<RT, EPI, false>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R, n_iter);
   return eagle_check_launch();
 }
 

@@ -48,6 +48,7 @@ class EagleDynamicDrafter:
         self.keep_debug, self.debug = keep_debug, []
         V = lm_head_weight.shape[0]
         self.caches = [model._cache_for(li, 1, self.cap, dev, None) for li in range(len(model.layers))]
+        model.set_cache_residency(self.lm_head)
         i32, i64, f32 = torch.int32, torch.int64, torch.float32
         self.len_cur = torch.zeros(1, dtype=i32, device=dev)
         self.len_nxt = torch.zeros(1, dtype=i32, device=dev)

@@ -180,6 +180,20 @@ class Llama2Model(nn.Module):
             self._packed[("gu", li)] = hit
         return hit[1]
 
+    def set_cache_residency(self, lm_head: Optional[torch.Tensor] = None, budget_mb: Optional[float] = None):
+        """Tell the weight-stream GEMM which of this model's matrices to keep in the Infinity Cache between
+        the draft forwards of a cycle: the smallest ones up to ``budget_mb`` (default 192 MB = 3/4 of the
+        256 MB cache; EAGLE_RESIDENT_MB overrides).  Called by the drafters; speed only."""
+        if budget_mb is None:
+            budget_mb = float(os.environ.get("EAGLE_RESIDENT_MB", "192"))
+        cands = [self.fc.weight]
+        for li, layer in enumerate(self.layers):
+            cands += [self._packed_weights(li), layer.self_attn.o_proj.weight, tuple(self._folded_mlp(li)),
+                      layer.mlp.down_proj.weight]
+        if lm_head is not None:
+            cands.append(lm_head)
+        ops.set_resident_weights(ops.pick_resident_weights(cands, int(budget_mb * 1e6))[:16])
+
     def _cache_for(self, li: int, B: int, need: int, device, past) -> _LayerCache:
         H, HK, hd = self._dims()
         while len(self._caches) <= li:

@@ -60,6 +60,29 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
+def set_resident_weights(weights) -> None:
+    """Name the weight matrices eagle_gemm_skinny_bf16 should keep cache-resident (see include/eagle_hip.h)."""
+    import ctypes
+    ws = list(weights)
+    arr = (ctypes.c_void_p * max(1, len(ws)))(*[w.data_ptr() for w in ws])
+    call("eagle_skinny_resident_weights", ctypes.cast(arr, ctypes.c_void_p), len(ws))
+
+
+def pick_resident_weights(weights, budget_bytes: int):
+    """Smallest-first subset of ``weights`` whose bytes fit ``budget_bytes`` (the Infinity Cache share a
+    draft forward's small matrices may occupy); groups (tuples) are taken or left whole."""
+    groups = [w if isinstance(w, (tuple, list)) else (w,) for w in weights]
+    groups.sort(key=lambda g: sum(t.numel() * t.element_size() for t in g))
+    out, used = [], 0
+    for g in groups:
+        b = sum(t.numel() * t.element_size() for t in g)
+        if used + b > budget_bytes:
+            break
+        out.extend(g)
+        used += b
+    return out
+
+
 def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
             out: Optional[torch.Tensor] = None, out_dtype=BF16, accumulate: bool = False, ksplit: int = 1) -> torch.Tensor:
     """C[M,N] = A[M,K] @ B[N,K]^T (+bias) (+res) on the LDS-tiled MFMA kernels.  ksplit > 1: split-K

@@ -62,6 +62,7 @@ class EagleDrafter:
         self.kv_bound = self.cap
         B, V = batch, lm_head_weight.shape[0]
         self.caches = [model._cache_for(li, B, self.cap, dev, None) for li in range(len(model.layers))]
+        model.set_cache_residency(self.lm_head)
         # draft KV-cache lengths: len_cur = rows before the catch-up forward, len_nxt = after it
         self.len_cur = torch.zeros(B, dtype=torch.int32, device=dev)
         self.len_nxt = torch.zeros(B, dtype=torch.int32, device=dev)

@@ -44,6 +44,14 @@ int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int
                            const void* res, int64_t ldr, void* out, int64_t ldo,
                            int M, int N, int K, int epi, eagle_stream_t stream);
 
+/* Cache-policy hint for eagle_gemm_skinny_bf16 (no counterpart in the reference: eager nn.Linear has no
+ * such knob): the listed weight matrices (device pointers as later passed in `W`, n <= 16; n = 0 clears)
+ * are streamed with the default cache policy so that they can stay in the 256 MB Infinity Cache from
+ * one draft forward to the next; every other weight is read with non-temporal loads.  Process-wide,
+ * set once by the host that owns the model (eagle_amd.speculative picks the smallest matrices up to
+ * a byte budget); a stale or missing list only changes speed, never results. */
+int eagle_skinny_resident_weights(const void* const* weights, int n);
+
 /* C[M,N] = epilogue(A[M,K] . B[N,K]^T): LDS-tiled MFMA GEMM (128x128x64 tiles, LDS-DMA staging)
  * for training-size M.  (+bias[N]) (+res[M,N] bf16); C is bf16 (out_f32 = 0) or fp32 (1);
  * accumulate != 0: C += result.  K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned bases.
