@@ -223,3 +223,57 @@ def test_chain_tree_is_the_reference_benchmark_setting():
             assert torch.equal(ids_g[0].cpu(), ids_o), f"cycle {cycle}: chain ids differ"
             prev_len += alen + 1
         drafter.check_errors()
+
+
+def test_kv_capacity_overflow_sets_the_error_flag_instead_of_faulting():
+    """A request that outgrows the draft KV cache must surface as HipKernelError at the next
+    check_errors() (the kernels bound-check against the capacity and skip the work), never as a fault."""
+    from eagle_amd import ops
+    from eagle_amd.speculative import EagleDrafter
+    d = dev()
+    dims = dm.DraftDims(hidden=256, inter=512, heads=2, kv_heads=2, vocab=500)
+    w = dm.init_weights(dims, seed=2, std=0.08)
+    g = torch.Generator().manual_seed(1)
+    lm_head = (torch.randn(dims.vocab, dims.hidden, generator=g) * 0.3).to(BF).to(d)
+    drafter = EagleDrafter(_model(dims, w), lm_head, batch=1, max_ctx=200)
+    assert drafter.cap == 256
+    ctx = 236                                   # + 6 catch-up rows + 11 tree rows fits 256 exactly once, not twice
+    tokens = torch.randint(0, dims.vocab, (1, ctx + 1), generator=g).to(d)
+    hidden = torch.randn(1, ctx, dims.hidden, generator=g).to(BF).to(d)
+    tb = ot.generate_tree_buffers()
+    with torch.no_grad():
+        drafter.prefill(hidden, tokens)
+        drafter.check_errors()                  # the first tree still fits
+        for _ in range(3):                      # every cycle accepts nothing: +1 row per cycle, tree rows on top
+            tgt = torch.zeros(1, tb.n_nodes, dims.vocab, dtype=BF, device=d)
+            tgt[..., 0] = 1.0
+            prev = torch.tensor([ctx], dtype=torch.int32, device=d)
+            drafter.verify(tokens[:, -1], tgt, prev)
+            acc = drafter.compact(prev, None, torch.zeros(1, tb.n_nodes, dims.hidden, dtype=BF, device=d))
+            drafter.draft(acc, drafter.next_ids)
+        drafter.check_errors()                  # 239 stable rows + 6 + 11 still fit
+        for _ in range(30):
+            drafter.verify(tokens[:, -1], tgt, prev)
+            drafter.draft(acc, drafter.next_ids)
+        assert int(drafter.stable_len[0]) > drafter.cap
+        with pytest.raises(ops._hip.HipKernelError):
+            drafter.check_errors()
+
+
+def test_single_token_prompt_and_batch_of_one_ragged():
+    from eagle_amd.speculative import EagleDrafter
+    d = dev()
+    dims = dm.DraftDims(hidden=256, inter=512, heads=2, kv_heads=2, vocab=500)
+    w = dm.init_weights(dims, seed=3, std=0.08)
+    g = torch.Generator().manual_seed(8)
+    lm_head = (torch.randn(dims.vocab, dims.hidden, generator=g) * 0.3).to(BF).to(d)
+    a = EagleDrafter(_model(dims, w), lm_head, batch=1, max_ctx=64)
+    b = EagleDrafter(_model(dims, w), lm_head, batch=1, max_ctx=64)
+    tok = torch.randint(0, dims.vocab, (2,), generator=g).to(d)
+    hid = torch.randn(1, dims.hidden, generator=g).to(BF).to(d)
+    with torch.no_grad():
+        ia, va = a.prefill(hid[None], tok[None])
+        ib, vb = b.prefill_ragged([hid], [tok])
+    assert torch.equal(ia, ib) and torch.equal(va, vb) and a.stable_len.tolist() == [1] == b.stable_len.tolist()
+    a.check_errors()
+    b.check_errors()
