@@ -18,25 +18,52 @@
 #define DT_MAXP 1024      // pool entries: k + (S-1) k^2
 #define DT_MAXT 64        // verified tree nodes incl. the root
 
-// lse[r] = log(sum_v exp(x[r][v])) in fp32, one workgroup per row (online max / sum per thread).
-__global__ __launch_bounds__(256) void row_lse_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, float* __restrict__ lse) {
-  __shared__ float sm[4], ss[4];
+// lse[r] = log(sum_v exp(x[r][v])) in fp32, one 1024-thread workgroup per row: 16-byte loads, an online
+// (max, sum) pair per thread updated once per 8 logits, wave then workgroup reduction.
+#define LSE_THREADS 1024
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+  const float M = fmaxf(m, m2);
+  if (M == -INFINITY) { m = M; s = 0.f; return; }
+  s = s * __expf(m - M) + s2 * __expf(m2 - M);
+  m = M;
+}
+__global__ __launch_bounds__(LSE_THREADS) void row_lse_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, float* __restrict__ lse) {
+  __shared__ float sm[LSE_THREADS / 64], ss[LSE_THREADS / 64];
   const bf16_t* xr = x + (int64_t)blockIdx.x * ld;
   float m = -INFINITY, s = 0.f;
-  for (int v = threadIdx.x; v < V; v += 256) {
-    const float f = bf2f(xr[v]);
-    if (f > m) { s = s * __expf(m - f) + 1.f; m = f; }
-    else if (f > -INFINITY) s += __expf(f - m);
+  const bool vec = ((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const int nv = vec ? (V >> 3) : 0;
+  for (int c = threadIdx.x; c < nv; c += LSE_THREADS) {
+    const uint4 q = *reinterpret_cast<const uint4*>(xr + 8 * c);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    float f[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = lo_bf(w[i]); f[2 * i + 1] = hi_bf(w[i]); }
+    float mx = f[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) mx = fmaxf(mx, f[i]);
+    if (mx > -INFINITY) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += __expf(f[i] - mx);
+      lse_merge(m, s, mx, acc);
+    }
   }
-  const float wm = wave_max(m);
-  s = (m > -INFINITY) ? s * __expf(m - wm) : 0.f;
-  s = wave_sum(s);
+  for (int v = 8 * nv + threadIdx.x; v < V; v += LSE_THREADS) {
+    const float f = bf2f(xr[v]);
+    if (f > -INFINITY) lse_merge(m, s, f, 1.f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+    lse_merge(m, s, m2, s2);
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { sm[wave] = wm; ss[wave] = s; }
+  if (lane == 0) { sm[wave] = m; ss[wave] = s; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    float M = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3])), S = 0.f;
-    for (int w = 0; w < 4; ++w) if (sm[w] > -INFINITY) S += ss[w] * __expf(sm[w] - M);
+    float M = -INFINITY, S = 0.f;
+    for (int w = 0; w < LSE_THREADS / 64; ++w) lse_merge(M, S, sm[w], ss[w]);
     lse[blockIdx.x] = M + __logf(S);
   }
 }
@@ -44,7 +71,7 @@ __global__ __launch_bounds__(256) void row_lse_kernel(const bf16_t* __restrict__
 extern "C" int eagle_row_lse_bf16(const void* logits, int64_t ld, int rows, int V, float* lse, hipStream_t stream) {
   if (!logits || !lse) return EAGLE_ERR_ARG;
   if (rows < 1 || V < 1 || ld < V) return EAGLE_ERR_SHAPE;
-  hipLaunchKernelGGL(row_lse_kernel, dim3(rows), dim3(256), 0, stream, (const bf16_t*)logits, ld, V, lse);
+  hipLaunchKernelGGL(row_lse_kernel, dim3(rows), dim3(LSE_THREADS), 0, stream, (const bf16_t*)logits, ld, V, lse);
   return eagle_check_launch();
 }
 

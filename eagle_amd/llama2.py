@@ -247,14 +247,20 @@ class Llama2Model(nn.Module):
             # indirection of the weight-stream GEMM covers one 64-row pass)
             emb_idx = ops.tree_gather_ids(emb_idx, emb_ind, B=B, batch_stride=emb_bstride).reshape(-1)
             emb_ind, emb_bstride = None, 0
+        # prompts and other wide row blocks without row gathers take the LDS-tiled MFMA GEMM for every
+        # projection: one weight pass instead of one per 64 rows of the weight-stream kernel
+        wide = M > 64 and hid_idx is None and emb_ind is None and x_width_ok(self, hid)
         # fc(cat(embed_tokens(ids), hidden)) -- eagle/llama2.py:515, :537-542
-        x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
-                              ind0=emb_ind, idx0_bstride=emb_bstride)
+        if wide:
+            x = ops.gemm_nt(ops.embed_concat(emb_w, emb_idx, hid), self.fc.weight, bias=self.fc.bias)
+        else:
+            x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
+                                  ind0=emb_ind, idx0_bstride=emb_bstride)
         for li, layer in enumerate(self.layers):
             a = layer.self_attn
             cache = caches[li]
             xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
-            qkv = ops.linear_skinny(xin, self._packed_weights(li))
+            qkv = ops.gemm_nt(xin, self._packed_weights(li)) if wide else ops.linear_skinny(xin, self._packed_weights(li))
             attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
             ws = self._attn_workspace(B, H, (past_host + q_len) if past_host is not None else max_kv, dev)
             for r0 in range(0, q_len, 16):
@@ -262,7 +268,7 @@ class Llama2Model(nn.Module):
                 bound = (past_host + r0 + mq) if past_host is not None else max_kv
                 ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, past_off0 + r0, tmask, pad, attn, ws,
                                    self._err, B, mq, H, HK, hd, bound, True, q_len, r0, pos_off, pos_stride)
-            x = ops.linear_skinny(attn, a.o_proj.weight, res=x)
+            x = ops.gemm_nt(attn, a.o_proj.weight, res=x) if wide else ops.linear_skinny(attn, a.o_proj.weight, res=x)
             # post_attention_layernorm fused into the gate/up projection: the norm weight is folded
             # into the weight columns, the row scale rsqrt(mean(x^2)+eps) is computed in-kernel
             if M > 64 and x.shape[1] % 64 == 0:
@@ -275,7 +281,10 @@ class Llama2Model(nn.Module):
             else:
                 wg, wu = self._folded_mlp(li)
                 act = ops.linear_skinny(x, wg, W2=wu, norm_eps=layer.post_attention_layernorm.variance_epsilon)
-            x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x)
+            if wide and act.shape[1] % 64 == 0:
+                x = ops.gemm_nt(act, layer.mlp.down_proj.weight, res=x)
+            else:
+                x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x)
         return x
 
     # ------------------------------------------------------------------ forward
@@ -354,6 +363,12 @@ class Llama2Model(nn.Module):
         if use_cache:
             return out, next_cache
         return out
+
+
+def x_width_ok(model, hid: torch.Tensor) -> bool:
+    """The MFMA GEMM wants K % 64 == 0 for every projection of the layer and contiguous hidden rows."""
+    D = model.config.hidden_size
+    return D % 64 == 0 and hid.dim() == 2 and hid.stride(1) == 1 and hid.shape[1] == D
 
 
 def _load_verifier_tensor(path, name: str) -> torch.Tensor:
