@@ -7,6 +7,7 @@ and cosine against the oracle run in fp32 on the same bf16-rounded weights (a bf
 reference differs from that fp32 truth by more than the kernels do; the test checks that too).
 Counts (agreement, masked tokens) are exact."""
 import copy
+import os
 
 import pytest
 import torch
@@ -328,3 +329,44 @@ def test_sharded_lm_head_loss_single_rank_equals_unsharded():
         parts.append(ops.gemm_nt(dlog, ops.transpose(w), out_dtype=torch.float32))
     d3 = ops.add_f32_bf16(parts[0] + parts[1], dpv)
     assert torch.allclose(s1, sums, rtol=1e-4) and rel_l2(d3, d1) < 4e-3
+
+
+def test_trainer_over_a_real_rccl_group_of_one_rank():
+    """The N > 1 code path on real RCCL (backend "nccl"), world size 1 -- the most this one-GPU box can
+    run: process-group init on the device, the token-count all-reduce, the asynchronous bucketed
+    AVG all-reduce of the flat bf16 gradient behind the last backward, the statistics all-reduce and
+    the vocab-sharded loss's exchange.  With one rank every collective is the identity, so the
+    updated parameters must equal those of the group-less trainer bit for bit."""
+    import socket
+
+    import torch.distributed as dist
+    from eagle_amd import train as T
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        mbs = [to_dev(make_batch(300 + i, 2, 64, p_mask=0.6)) for i in range(2)]
+        res = []
+        for group in (None, dist.group.WORLD):
+            model, wb, lm_head = make_model(seed=11)
+            tr = T.EagleTrainer(model, lm_head.to(DEV), lr=1e-3, grad_clip=0.02, num_warmup_steps=2, num_training_steps=10,
+                                mode="dp", group=group, world_size=1)
+            for _ in range(2):
+                out = tr.step(mbs)
+            torch.cuda.synchronize()
+            res.append((tr.flat.clone(), out["sums"].clone(), out["num_items"]))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
+        # vocab-sharded loss with a one-rank group == the unsharded loss
+        model, wb, lm_head = make_model(seed=12)
+        lm = lm_head.to(DEV)
+        g = torch.Generator().manual_seed(5)
+        pr, tg = torch.randn(96, DIMS.hidden, generator=g).to(BF).to(DEV), torch.randn(96, DIMS.hidden, generator=g).to(BF).to(DEV)
+        mask = (torch.rand(96, generator=g) < 0.7).float().to(DEV)
+        sh = T.ShardedLmHeadLoss(lm, 0, dist.group.WORLD, 1, 0)
+        s1, d1 = sh.fwd_bwd(pr, tg, mask, 1.0, 0.1, 0.01)
+        s0, d0 = T.loss_fwd_bwd(pr, tg, lm, lm.t().contiguous(), mask, 1.0, 0.1, 0.01)
+        assert torch.allclose(s1, s0, rtol=1e-5, atol=1e-5) and rel_l2(d1, d0) < 1e-2
+    finally:
+        dist.destroy_process_group()
