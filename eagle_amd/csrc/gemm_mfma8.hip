@@ -46,6 +46,7 @@ struct Gemm8Args {
   int M, N, K;
   int out_f32, accumulate;
   int tiles_m, tiles_n;
+  int gm;              // row tiles per group of the tile order
   int ksplit;          // > 1: grid = tiles x ksplit, slice s multiplies K tiles [s*kchunk, ...) into partial[s]
   int kchunk;          // K tiles per slice
   float* partial;      // [ksplit][M][N] fp32 (split-K only)
@@ -106,7 +107,13 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   const int wgid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   const int kslice = wgid0 / ntile;                 // slices of one tile sit ntile ids apart
   const int wgid = wgid0 - kslice * ntile;
-  const int tn = wgid / p.tiles_m, tm = wgid - tn * p.tiles_m;
+  // grouped order: consecutive ids sweep `gm` row tiles, then move one column tile on, so the 32 tiles an
+  // XCD runs at a time form a gm x (32/gm) block (fewer distinct A/B slices per K step in its L2)
+  const int per_group = p.gm * p.tiles_n;
+  const int grp = wgid / per_group, in_grp = wgid - grp * per_group;
+  const int first_m = grp * p.gm;
+  const int gsz = min(p.tiles_m - first_m, p.gm);
+  const int tn = in_grp / gsz, tm = first_m + (in_grp - tn * gsz);
   const int m0 = tm * G8_BM, n0 = tn * G8_BN;
 
   f32x4 acc[8][4];
@@ -319,6 +326,8 @@ __global__ __launch_bounds__(256) void gemm8_reduce_kernel(Gemm8Args p) {
   }
 }
 
+static int g_g8_gm = -1;           // EAGLE_GEMM8_GM: row tiles per group (0 = all rows, the plain column-major order)
+extern "C" void eagle_debug_set_gemm8_gm(int gm) { g_g8_gm = gm; }
 static int g_g8_pingpong = -1;     // EAGLE_GEMM8_PINGPONG=0 selects the in-phase schedule (A/B measurements)
 extern "C" void eagle_debug_set_gemm8_pingpong(int on) { g_g8_pingpong = on; }
 
@@ -339,6 +348,8 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
   a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = (N + G8_BN - 1) / G8_BN;
+  if (g_g8_gm < 0) { const char* e = getenv("EAGLE_GEMM8_GM"); g_g8_gm = e ? atoi(e) : 8; }
+  a.gm = (g_g8_gm <= 0 || g_g8_gm > a.tiles_m) ? a.tiles_m : g_g8_gm;
   if (g_g8_pingpong < 0) { const char* e = getenv("EAGLE_GEMM8_PINGPONG"); g_g8_pingpong = e ? atoi(e) : 1; }
   if (g_g8_pingpong >= 16) {      // timing experiments (tools/gemm_bench.py): 16 + DBG bits
     const dim3 gr(a.tiles_m * a.tiles_n * a.ksplit), bl(G8_THREADS);
