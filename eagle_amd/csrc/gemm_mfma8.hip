@@ -185,7 +185,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
     // S7(t) ends one barrier before the early group's S1(t+1).
     if (wr == 1) __builtin_amdgcn_s_barrier();
     // DBG (timing experiments only, results invalid): bit 0 = no DMA in the loop, bit 1 = no LDS reads,
-    // bit 2 = no barriers, bit 3 = DMA always from the first two K tiles (cache-hot), bit 4 = no vmcnt wait
+    // bit 2 = no barriers, bit 3 = DMA always from the first two K tiles (cache-hot), bit 4 = no vmcnt wait, bit 6 = no output stores
 #define G8_BAR() do { if (!(DBG & 4)) __builtin_amdgcn_s_barrier(); } while (0)
     if (DBG & 2) { read_b(hbuf(0, 2 + (wc >> 1)), 0, bf0); read_a(hbuf(0, wr), 0); read_b(hbuf(0, 2 + (wc >> 1)), 1, bf1); }
     for (int t = 0; t < nk; ++t) {
@@ -241,6 +241,12 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the never-consumed tail stages must land before the LDS is released
 #undef G8_MFMA
 
+  if (DBG & 64) {      // timing experiment: no output stores (one impossible store keeps the accumulators alive)
+    float sum = 0.f;
+    for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 12345.678f) ((float*)p.C)[0] = sum;
+    return;
+  }
   // epilogue: acc[i][j][r] = C[m0 + wr*128 + i*16 + r16][n0 + wc*64 + j*16 + 4g + r]
   if (p.ksplit > 1) {                               // split-K: raw fp32 partial sums; gemm8_reduce_kernel finishes
     float* part = p.partial + (int64_t)kslice * p.M * p.N;
@@ -255,6 +261,52 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
         if (nb + 3 < p.N && (p.N & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         else for (int rr = 0; rr < 4; ++rr) if (nb + rr < p.N) o[rr] = acc[i][j][rr];
       }
+    }
+    return;
+  }
+  // Interior tiles with bf16 output: the accumulators go through the (now free) LDS so that every store
+  // instruction writes whole 128-byte row segments (8 rows x 128 B per wave-instruction, 16 B per lane)
+  // instead of 16 rows x 32 B -- a quarter of the write requests, and the residual is read the same way.
+  const bool coalesced = !p.out_f32 && !p.accumulate && (m0 + G8_BM <= p.M) && (n0 + G8_BN <= p.N) && ((p.ldc & 7) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                         (!p.res || (((p.ldr & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
+  if (coalesced) {
+    __builtin_amdgcn_s_barrier();                   // every wave's tail DMA has landed (vmcnt(0) above): the LDS is free
+    constexpr int LDW = 72;                         // 64 columns + 8 of padding: 144-byte rows keep b128 reads aligned
+    bf16_t* st = lds + wave * (64 * LDW);           // 64 rows per pass, private to the wave
+    const int lrow = lane >> 3, lch = lane & 7;
+    float bv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) bv[j][rr] = p.bias ? bf2f(p.bias[n0 + wc * 64 + j * 16 + 4 * g + rr]) : 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 a = acc[half * 4 + i][j];
+          *reinterpret_cast<uint2*>(st + (i * 16 + r16) * LDW + j * 16 + 4 * g) =
+              make_uint2(pack2bf(a[0] + bv[j][0], a[1] + bv[j][1]), pack2bf(a[2] + bv[j][2], a[3] + bv[j][3]));
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q8 = 0; q8 < 8; ++q8) {
+        const int row = q8 * 8 + lrow;
+        uint4 v = *reinterpret_cast<const uint4*>(st + row * LDW + lch * 8);
+        const int64_t grow = m0 + wr * 128 + half * 64 + row;
+        const int gcol = n0 + wc * 64 + lch * 8;
+        if (p.res) {
+          const uint4 rv = *reinterpret_cast<const uint4*>(p.res + grow * p.ldr + gcol);
+          v.x = pack2bf(lo_bf(v.x) + lo_bf(rv.x), hi_bf(v.x) + hi_bf(rv.x));
+          v.y = pack2bf(lo_bf(v.y) + lo_bf(rv.y), hi_bf(v.y) + hi_bf(rv.y));
+          v.z = pack2bf(lo_bf(v.z) + lo_bf(rv.z), hi_bf(v.z) + hi_bf(rv.z));
+          v.w = pack2bf(lo_bf(v.w) + lo_bf(rv.w), hi_bf(v.w) + hi_bf(rv.w));
+        }
+        *reinterpret_cast<uint4*>((bf16_t*)p.C + grow * p.ldc + gcol) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
     return;
   }
@@ -361,6 +413,7 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
       case 8: hipLaunchKernelGGL((gemm_nt8_kernel<true, 8>), gr, bl, 0, stream, a); break;
       case 16: hipLaunchKernelGGL((gemm_nt8_kernel<true, 16>), gr, bl, 0, stream, a); break;
       case 24: hipLaunchKernelGGL((gemm_nt8_kernel<true, 24>), gr, bl, 0, stream, a); break;
+      case 64: hipLaunchKernelGGL((gemm_nt8_kernel<true, 64>), gr, bl, 0, stream, a); break;
       default: return EAGLE_ERR_ARG;
     }
   } else if (g_g8_pingpong) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);

@@ -10,7 +10,7 @@ setm(1)
 for M, N, K, name in [(4096, 151936, 4096, 'lm_head qwen'), (4096, 24576, 4096, 'gate|up'), (4096, 4096, 12288, 'down'), (8192, 8192, 8192, '8k cube')]:
     A = torch.randn(M, K, device=dev).to(torch.bfloat16); B = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    for mode, label in ((1, 'full'), (17, 'no DMA'), (18, 'no LDS reads'), (19, 'no DMA, no reads'), (23, 'MFMA only (no barriers)'), (24, 'DMA from 2 hot K tiles'), (32, 'DMA, no vmcnt wait'), (40, 'hot DMA, no wait')):
+    for mode, label in ((1, 'full'), (17, 'no DMA'), (18, 'no LDS reads'), (19, 'no DMA, no reads'), (23, 'MFMA only (no barriers)'), (24, 'DMA from 2 hot K tiles'), (32, 'DMA, no vmcnt wait'), (40, 'hot DMA, no wait'), (80, 'no output stores')):
         setpp(mode)
         for _ in range(3): ops.gemm_nt(A, B, out=C)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
