@@ -310,6 +310,41 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
     }
     return;
   }
+  // The same for C += result (weight gradients of the second and later micro-batches): fp32 staging, 32 rows
+  // per pass, so that the sum is rounded once exactly as in the generic path below.
+  const bool coalesced_acc = !p.out_f32 && p.accumulate && !p.res && !p.bias && (m0 + G8_BM <= p.M) && (n0 + G8_BN <= p.N) &&
+                             ((p.ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+  if (coalesced_acc) {
+    __builtin_amdgcn_s_barrier();
+    constexpr int LDF = 68;                         // 64 floats + 4 of padding (272-byte rows)
+    float* stf = reinterpret_cast<float*>(lds) + wave * (32 * LDF);
+    const int lrow = lane >> 3, lch = lane & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(stf + (i * 16 + r16) * LDF + j * 16 + 4 * g) = acc[q * 2 + i][j];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q8 = 0; q8 < 4; ++q8) {
+        const int row = q8 * 8 + lrow;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(stf + row * LDF + lch * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(stf + row * LDF + lch * 8 + 4);
+        bf16_t* o = (bf16_t*)p.C + (int64_t)(m0 + wr * 128 + q * 32 + row) * p.ldc + n0 + wc * 64 + lch * 8;
+        const uint4 old = *reinterpret_cast<const uint4*>(o);
+        uint4 v;
+        v.x = pack2bf(lo[0] + lo_bf(old.x), lo[1] + hi_bf(old.x));
+        v.y = pack2bf(lo[2] + lo_bf(old.y), lo[3] + hi_bf(old.y));
+        v.z = pack2bf(hi[0] + lo_bf(old.z), hi[1] + hi_bf(old.z));
+        v.w = pack2bf(hi[2] + lo_bf(old.w), hi[3] + hi_bf(old.w));
+        *reinterpret_cast<uint4*>(o) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int m = m0 + wr * 128 + i * 16 + r16;

@@ -506,6 +506,17 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
               (ref + bias.float()).to(BF).float() + res.float(), what="gemm8 bias+res")
         ya = ops.gemm_nt(A.to(dev()), Bm.to(dev()), out=acc.to(dev()).clone(), accumulate=True)
         close(ya, acc + ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="gemm8 accumulate")
+        # bf16 accumulate (the weight-gradient buffers): interior tiles take the coalesced epilogue, edge tiles
+        # the generic one; both round the fp32 sum once, so the two kernels agree bit for bit
+        accb = acc.to(BF)
+        yb = ops.gemm_nt(A.to(dev()), Bm.to(dev()), out=accb.to(dev()).clone(), accumulate=True)
+        close(yb, accb.float() + ref, what="gemm8 bf16 accumulate")
+        setm(0)
+        yb128 = ops.gemm_nt(A.to(dev()), Bm.to(dev()), out=accb.to(dev()).clone(), accumulate=True)
+        assert torch.equal(yb, yb128)
+        ybr128 = ops.gemm_nt(A.to(dev()), Bm.to(dev()), bias=bias.to(dev()), res=res.to(dev()))
+        setm(1)
+        assert torch.equal(ybr128, ops.gemm_nt(A.to(dev()), Bm.to(dev()), bias=bias.to(dev()), res=res.to(dev())))
         setm(0)
         y128 = ops.gemm_nt(A.to(dev()), Bm.to(dev()), out_dtype=torch.float32)
         setm(1)
