@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--config", default="llama2_7b", choices=["llama2_7b", "qwen3_8b"])
     ap.add_argument("--expand", default="wchild", choices=["wchild", "all"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cycles-per-graph", type=int, default=1, help="draft/verify cycles captured into one HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--no-batched", action="store_true", help="skip the batch-32 configs[3] leg")
@@ -100,7 +101,7 @@ class SyntheticVerifier:
 
 
 def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, plant_prob, tgt_kv, graph=False, timed_from=0,
-               timed_n=0, sync=None):
+               timed_n=0, sync=None, per_graph=1):
     """Closed-loop generation.  The verifier's per-cycle outputs sit in a ring in HBM whose cursor
     is advanced on the device by the verify chain, so the timed region holds nothing but the hot
     path.  Returns (final state, accepted tokens over the timed span, elapsed seconds of it)."""
@@ -122,7 +123,11 @@ def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, pla
     elapsed = 0.0
     t0 = None
     len0 = len1 = None
+    G = per_graph if (graph and not record and per_graph > 1 and (timed_from - 2) % per_graph == 0 and timed_n % per_graph == 0
+                      and (n_cycles - 2) % per_graph == 0 and timed_from >= 2) else 1
     for c in range(n_cycles):
+        if G > 1 and c >= 2 and (c - 2) % G:
+            continue                                 # cycles 2.. run G at a time inside one graph replay
         if record:
             tok = torch.cat([root, drafter.flat_ids[0].reshape(-1)])[drafter.tb.tree_indices]
             ver.plant(c, tok.cpu(), drafter.tb, plant_prob)
@@ -136,7 +141,8 @@ def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, pla
                 g = torch.cuda.CUDAGraph()
                 # thread_local: a process group's watchdog thread may touch the runtime during the capture
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    one_cycle()          # capture does not execute: replay below runs this cycle
+                    for _ in range(G):
+                        one_cycle()      # capture does not execute: replay below runs these cycles
                 g.replay()
             elif g is not None:
                 g.replay()
@@ -144,7 +150,7 @@ def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, pla
                 one_cycle()
         else:
             one_cycle()
-        if timed_n and c == timed_from + timed_n - 1:
+        if timed_n and c == timed_from + timed_n - G:
             sync()
             elapsed = time.perf_counter() - t0
             len1 = prev_len.clone()
@@ -457,7 +463,8 @@ def main():
     with torch.no_grad():
         rec_final, _, _ = run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, True, a.plant, tgt_kv)
         final, accepted, elapsed = run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, False, a.plant, tgt_kv,
-                                              graph=not a.no_graph, timed_from=a.warmup, timed_n=a.steps, sync=sync)
+                                              graph=not a.no_graph, timed_from=a.warmup, timed_n=a.steps, sync=sync,
+                                              per_graph=a.cycles_per_graph)
     if final != rec_final:
         raise SystemExit(f"timed replay diverged from the recorded generation: {final} vs {rec_final}")
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)

@@ -657,3 +657,71 @@ def test_verify_ring_cursor_matches_direct_buffers():
     for a, b in zip(*runs):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
+
+
+# ------------------------------------------------------------------ BASELINE full sizes, by properties
+def test_fused_loss_full_size_properties():
+    """configs[2] size (N = 2048 tokens, V = 151936): the CPU oracle is too slow here, so the fused loss is
+    held to size-independent properties, with plain fp32 torch on the device as the arithmetic check:
+    rows of dlogits sum to zero (softmax(o) - p, both normalised), masked rows are exactly zero, the
+    loss equals -sum p.log q, the agreement count equals first-argmax equality, and the vocabulary split
+    into 8 shards combines to the same statistics (configs[4])."""
+    from eagle_amd import ops
+    d = dev()
+    N, V, D = 2048, 151936, 4096
+    g = torch.Generator(device=d).manual_seed(9)
+    t = (torch.randn((N, V), generator=g, device=d) * 2).to(BF)
+    o = (t.float() * 0.5 + torch.randn((N, V), generator=g, device=d)).to(BF)
+    o[:64] = t[:64]                                                   # rows that agree
+    predict = torch.randn((N, D), generator=g, device=d).to(BF)
+    target = (predict.float() + 0.5 * torch.randn((N, D), generator=g, device=d)).to(BF)
+    mask = (torch.rand(N, generator=g, device=d) < 0.7).float()
+    stats = ops.ce_partial(t, o, 0, predict, target)
+    sums, lse_t, lse_o, rows = ops.ce_combine(stats, mask)
+    ref_pl = torch.zeros((), device=d, dtype=torch.float64)
+    agree = 0
+    for r0 in range(0, N, 256):                                       # fp32 torch reference in row blocks (memory)
+        tf, of = t[r0:r0 + 256].float(), o[r0:r0 + 256].float()
+        p, lq = torch.softmax(tf, -1), torch.log_softmax(of, -1)
+        ref_pl += (-(p * lq).sum(-1) * mask[r0:r0 + 256]).sum().double()
+        st = torch.sort(tf, dim=-1, descending=True, stable=True).indices[:, 0]
+        so = torch.sort(of, dim=-1, descending=True, stable=True).indices[:, 0]
+        agree += int(((st == so).float() * mask[r0:r0 + 256]).sum())
+    assert abs(float(sums[0]) - float(ref_pl)) <= 1e-3 * abs(float(ref_pl))
+    assert int(sums[2]) == agree and int(sums[3]) == int(mask.sum()) and agree >= int(mask[:64].sum())
+    dl, dp = ops.ce_smoothl1_bwd(t, o, lse_t, lse_o, mask, 0.1 / N, 1.0 / N, predict, target)
+    rs = dl.float().sum(-1)
+    ra = dl.float().abs().sum(-1)
+    assert float((rs.abs() - 2e-2 * ra).max()) <= 1e-7               # bf16 rounding of each element: a few % of the row's mass
+    assert float(dl[mask == 0].float().abs().max()) == 0.0 and float(dp[mask == 0].float().abs().max()) == 0.0
+    # vocabulary shards (8 ranks' local statistics) combine to the unsharded result
+    bounds = [(r * 19008, min(V, (r + 1) * 19008)) for r in range(8)]
+    parts = torch.stack([ops.ce_partial(t[:, a:b], o[:, a:b], a, predict if i == 0 else None, target if i == 0 else None)
+                         for i, (a, b) in enumerate(bounds)])
+    s8, lt8, lo8, _ = ops.ce_combine(parts, mask)
+    assert torch.allclose(s8[:1], sums[:1], rtol=1e-5) and int(s8[2]) == int(sums[2]) and torch.allclose(lt8, lse_t, atol=1e-4)
+    assert torch.allclose(lo8, lse_o, atol=1e-4)
+
+
+def test_topk_full_vocab_properties():
+    """26 verifier rows x V = 151936 (the verify step of configs[3]) and 8 draft rows: values sorted
+    descending, ids strictly ascending inside every run of equal values, every other logit <= the k-th
+    value, ids unique -- and equality with the stable sort on a sample of rows."""
+    from eagle_amd import ops
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(3)
+    x = (torch.randn((26, 151936), generator=g, device=d) * 2).to(BF)
+    vals, ids = ops.topk(x, 10)
+    v, i = vals.float(), ids
+    assert bool((v[:, :-1] >= v[:, 1:]).all())
+    same = v[:, :-1] == v[:, 1:]
+    assert bool((i[:, :-1][same] < i[:, 1:][same]).all())
+    assert all(len(set(r)) == 10 for r in i.tolist())
+    assert torch.equal(x.gather(1, i), vals)
+    rest = x.float().clone()
+    rest.scatter_(1, i, float("-inf"))
+    assert bool((rest.max(dim=1).values <= v[:, -1]).all())
+    for r in (0, 13, 25):
+        assert torch.equal(i[r].cpu(), ot.stable_topk(x[r].cpu(), 10)[1])
+    am = ops.first_argmax(x)
+    assert torch.equal(am, i[:, 0])
