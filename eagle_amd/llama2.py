@@ -249,10 +249,11 @@ class Llama2Model(nn.Module):
             emb_ind, emb_bstride = None, 0
         # prompts and other wide row blocks without row gathers take the LDS-tiled MFMA GEMM for every
         # projection: one weight pass instead of one per 64 rows of the weight-stream kernel
-        wide = M > 64 and hid_idx is None and emb_ind is None and x_width_ok(self, hid)
+        wide_rest = M > 64 and x_width_ok(self, hid)                  # qkv / o / gate|up / down: no row gathers involved
+        wide = wide_rest and hid_idx is None and emb_ind is None      # fc too
         # fc(cat(embed_tokens(ids), hidden)) -- eagle/llama2.py:515, :537-542
         if wide:
-            x = ops.gemm_nt(ops.embed_concat(emb_w, emb_idx, hid), self.fc.weight, bias=self.fc.bias)
+            x = _gemm_wide(ops.embed_concat(emb_w, emb_idx, hid), self.fc.weight, bias=self.fc.bias)
         else:
             x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
                                   ind0=emb_ind, idx0_bstride=emb_bstride)
@@ -260,7 +261,7 @@ class Llama2Model(nn.Module):
             a = layer.self_attn
             cache = caches[li]
             xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
-            qkv = ops.gemm_nt(xin, self._packed_weights(li)) if wide else ops.linear_skinny(xin, self._packed_weights(li))
+            qkv = _gemm_wide(xin, self._packed_weights(li)) if wide_rest else ops.linear_skinny(xin, self._packed_weights(li))
             attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
             ws = self._attn_workspace(B, H, (past_host + q_len) if past_host is not None else max_kv, dev)
             for r0 in range(0, q_len, 16):
@@ -268,7 +269,7 @@ class Llama2Model(nn.Module):
                 bound = (past_host + r0 + mq) if past_host is not None else max_kv
                 ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, past_off0 + r0, tmask, pad, attn, ws,
                                    self._err, B, mq, H, HK, hd, bound, True, q_len, r0, pos_off, pos_stride)
-            x = ops.gemm_nt(attn, a.o_proj.weight, res=x) if wide else ops.linear_skinny(attn, a.o_proj.weight, res=x)
+            x = _gemm_wide(attn, a.o_proj.weight, res=x) if wide_rest else ops.linear_skinny(attn, a.o_proj.weight, res=x)
             # post_attention_layernorm fused into the gate/up projection: the norm weight is folded
             # into the weight columns, the row scale rsqrt(mean(x^2)+eps) is computed in-kernel
             if M > 64 and x.shape[1] % 64 == 0:
@@ -276,13 +277,12 @@ class Llama2Model(nn.Module):
                 # instead of one weight-stream pass per 32 rows
                 n = ops.rmsnorm(x, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
                 wgu = self._stacked_mlp(li)
-                tiles = ((M + 255) // 256) * ((wgu.shape[0] + 255) // 256)
-                act = ops.silu_mul(ops.gemm_nt(n, wgu, ksplit=2 if tiles <= 128 else 1))
+                act = ops.silu_mul(_gemm_wide(n, wgu))
             else:
                 wg, wu = self._folded_mlp(li)
                 act = ops.linear_skinny(x, wg, W2=wu, norm_eps=layer.post_attention_layernorm.variance_epsilon)
-            if wide and act.shape[1] % 64 == 0:
-                x = ops.gemm_nt(act, layer.mlp.down_proj.weight, res=x)
+            if wide_rest and act.shape[1] % 64 == 0:
+                x = _gemm_wide(act, layer.mlp.down_proj.weight, res=x)
             else:
                 x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x)
         return x
@@ -363,6 +363,16 @@ class Llama2Model(nn.Module):
         if use_cache:
             return out, next_cache
         return out
+
+
+def _gemm_wide(x: torch.Tensor, W: torch.Tensor, bias=None, res=None) -> torch.Tensor:
+    """x[M,K] . W[N,K]^T on the 256x256 MFMA GEMM for 64 < M rows: one weight pass.  With few output tiles
+    (M <= 256 rows against N = 4096 is 16 tiles for 256 CUs) K is split so that about one round of
+    workgroups streams the weights, at the price of fp32 partials (ksplit * M * N * 8 bytes of traffic)."""
+    M, K = x.shape
+    tiles = ((M + 255) // 256) * ((W.shape[0] + 255) // 256)
+    ksplit = max(1, min(8, 256 // tiles, K // 256))
+    return ops.gemm_nt(x, W, bias=bias, res=res, ksplit=ksplit)
 
 
 def x_width_ok(model, hid: torch.Tensor) -> bool:
