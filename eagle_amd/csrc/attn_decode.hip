@@ -8,14 +8,11 @@
 // transpose back to [B, q, H*hd] (:272-273).
 //
 // Split-KV ("flash-decoding") layout so that a batch-1 request still fills the chip:
-//   one workgroup per (64-key chunk, head, request).  K rows stream HBM/L2 -> VGPR as
-//   MFMA A fragments (v_mfma_f32_16x16x32_bf16: keys x queries), chunk-local softmax
-//   in fp32, P.V on the VALU with every V load of the chunk in flight at once;
-//   writes (m, l, O~) partials, releases them at agent scope and takes an arrival ticket of its
-//   (head, request); the workgroup that draws the last ticket acquires, merges the partials and
-//   writes the bf16 rows (no second launch).  The tickets live in the first AD_CTR_BYTES of the
-//   workspace: zero before the first call, left zero by every call.
-//   (attn_combine_kernel, the two-launch form's merge, is kept behind eagle_debug_set_attn_fused(0).)
+//   kernel 1: one workgroup per (64-key chunk, head, request).  K rows stream HBM/L2 -> VGPR as
+//             MFMA A fragments (v_mfma_f32_16x16x32_bf16: keys x queries), chunk-local softmax
+//             in fp32, P.V on the VALU with every V load of the chunk in flight at once;
+//             writes (m, l, O~) partials.
+//   kernel 2: one workgroup per (head, request) merges the partials and writes bf16 rows.
 // q/k RoPE roundings follow the reference's bf16 eager op order; scores are rounded to bf16
 // before and after the 1/sqrt(hd) scaling like the reference; the probabilities stay fp32 (the
 // reference rounds them to bf16) -- inside the stated bf16 tolerance.
@@ -25,7 +22,6 @@
 #define AD_MAXM 16
 #define AD_MAXHD 128
 #define AD_CH 64  // keys per workgroup
-#define AD_CMAX 8  // partial records loaded per batch in the merge
 
 struct AttnDecArgs {
   const bf16_t* qkv; int64_t ld_qkv;
@@ -37,7 +33,6 @@ struct AttnDecArgs {
   const uint8_t* pad_mask; int64_t pm_stride;
   bf16_t* out; int64_t ld_out;
   float* ws; int max_splits;
-  int* tickets; int fused;
   int* err_flag;
   int B, M, H, HK, hd, cap, causal;
   int rows_per_req, row_off;  // row of request b, query m = b*rows_per_req + row_off + m
@@ -47,9 +42,6 @@ struct AttnDecArgs {
 
 // workspace record per (b, h, split): [AD_MAXM][AD_MAXHD] fp32 O~  then [AD_MAXM][2] fp32 (m, l)
 #define AD_REC (AD_MAXM * AD_MAXHD + AD_MAXM * 2)
-// arrival tickets, one int per (request, head), at the start of the workspace
-#define AD_CTR_BYTES 65536
-#define AD_CTR_MAX (AD_CTR_BYTES / 4)
 
 __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t q_s[AD_MAXM * AD_MAXHD];
@@ -309,72 +301,11 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
     }
     if (t < M) { rec[AD_MAXM * AD_MAXHD + 2 * t] = rowm[t]; rec[AD_MAXM * AD_MAXHD + 2 * t + 1] = rowl[t]; }
   }
-  if (!p.fused) return;
-
-  // ---- phase 4: arrival ticket; the last workgroup of this (request, head) merges the partials ----
-  __shared__ int last_s;
-  const int ns = (total + AD_CH - 1) / AD_CH;    // workgroups of this (b, h) that reach this point
-  // hand-off (cdna_hip_programming.md, Guideline 16, counter form): every wave drains its stores, barrier, one lane
-  // releases at agent scope and takes the ticket; the last arriver acquires at agent scope, barrier, plain loads
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (t == 0) {
-    int* tk = p.tickets + b * p.H + h;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int prev = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = prev == ns - 1;
-    if (last) {
-      __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all ns tickets drawn: ready for the next call
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    last_s = last;
-  }
-  __syncthreads();
-  if (!last_s) return;
-  const float* base = p.ws + (int64_t)(b * p.H + h) * p.max_splits * AD_REC;
-  float* wgt = &red[0][0][0];                     // [ns][AD_MAXM] merge weights w_s / sum_s(w_s l_s); red is free (barriers above)
-  if (ns * AD_MAXM <= 4 * AD_MAXM * AD_MAXHD) {
-    if (t < M) {
-      float mx = -INFINITY;
-      for (int s = 0; s < ns; ++s) mx = fmaxf(mx, base[(int64_t)s * AD_REC + AD_MAXM * AD_MAXHD + 2 * t]);
-      float l = 0.f;
-      for (int s = 0; s < ns; ++s) {
-        const float ms = base[(int64_t)s * AD_REC + AD_MAXM * AD_MAXHD + 2 * t];
-        const float w = (ms > -INFINITY) ? __expf(ms - mx) : 0.f;
-        l += w * base[(int64_t)s * AD_REC + AD_MAXM * AD_MAXHD + 2 * t + 1];
-        wgt[s * AD_MAXM + t] = w;
-      }
-      const float inv = l > 0.f ? 1.f / l : 0.f;
-      for (int s = 0; s < ns; ++s) wgt[s * AD_MAXM + t] *= inv;
-    }
-    __syncthreads();
-    const int q4 = hd >> 2;                       // hd % 8 == 0: float4 items
-    for (int i = t; i < M * q4; i += AD_THREADS) {
-      const int m = i / q4, d = (i - m * q4) << 2;
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int s0 = 0; s0 < ns; s0 += AD_CMAX) {
-        float4 r[AD_CMAX];
-#pragma unroll
-        for (int u = 0; u < AD_CMAX; ++u) {
-          const int sidx = s0 + u < ns ? s0 + u : ns - 1;
-          r[u] = *reinterpret_cast<const float4*>(base + (int64_t)sidx * AD_REC + m * AD_MAXHD + d);
-        }
-#pragma unroll
-        for (int u = 0; u < AD_CMAX; ++u) {
-          const float w = s0 + u < ns ? wgt[(s0 + u) * AD_MAXM + m] : 0.f;
-          o.x += w * r[u].x; o.y += w * r[u].y; o.z += w * r[u].z; o.w += w * r[u].w;
-        }
-      }
-      bf16_t* orow = p.out + ((int64_t)b * p.rows_per_req + p.row_off + m) * p.ld_out + h * hd + d;
-      *reinterpret_cast<uint2*>(orow) = make_uint2(pack2bf(o.x, o.y), pack2bf(o.z, o.w));
-    }
-  }
 }
 
 // grid (H, B, ceil(M/2)); 256 threads = 2 rows x 128 d.  All partial loads of a row are issued
 // before they are used (two independent passes over <= max_splits records).
+#define AD_CMAX 8
 __global__ __launch_bounds__(2 * AD_MAXHD) void attn_combine_kernel(AttnDecArgs p) {
   const int h = blockIdx.x, b = blockIdx.y;
   const int d = threadIdx.x & (AD_MAXHD - 1), m = blockIdx.z * 2 + (threadIdx.x >> 7);
@@ -416,12 +347,8 @@ __global__ __launch_bounds__(2 * AD_MAXHD) void attn_combine_kernel(AttnDecArgs 
 }
 
 extern "C" int64_t eagle_attn_decode_workspace_bytes(int B, int H, int max_kv) {
-  return AD_CTR_BYTES + (int64_t)B * H * ((max_kv + AD_CH - 1) / AD_CH) * AD_REC * sizeof(float);
+  return (int64_t)B * H * ((max_kv + AD_CH - 1) / AD_CH) * AD_REC * sizeof(float);
 }
-
-static int g_attn_fused = 1;
-// debug / test switch: 0 = the two-launch form (split kernel, then attn_combine_kernel)
-extern "C" void eagle_debug_set_attn_fused(int on) { g_attn_fused = on; }
 
 // See include/eagle_hip.h for the contract.
 extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const int64_t* position_ids, int pos_off,
@@ -446,11 +373,7 @@ extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const 
   a.past_len = past_len; a.past_off = past_off;
   a.tree_mask = tree_mask; a.T = tree_mask ? T : 0; a.tm_bstride = tree_mask_batch_stride;
   a.pad_mask = pad_mask; a.pm_stride = pad_mask_stride;
-  a.out = (bf16_t*)out; a.ld_out = ld_out; a.max_splits = (max_kv + AD_CH - 1) / AD_CH;
-  a.tickets = (int*)workspace; a.ws = (float*)((char*)workspace + AD_CTR_BYTES);
-  // the merge needs 8-byte aligned output rows, one ticket per (request, head) and its weights in LDS
-  a.fused = g_attn_fused && (int64_t)B * H <= AD_CTR_MAX && a.max_splits <= 4 * AD_MAXHD && (ld_out & 3) == 0 &&
-            (reinterpret_cast<uintptr_t>(out) & 7) == 0;
+  a.out = (bf16_t*)out; a.ld_out = ld_out; a.ws = (float*)workspace; a.max_splits = (max_kv + AD_CH - 1) / AD_CH;
   a.err_flag = err_flag;
   a.B = B; a.M = M; a.H = H; a.HK = HK; a.hd = hd; a.cap = cap; a.causal = causal;
   a.rows_per_req = rows_per_req; a.row_off = row_off;
@@ -460,7 +383,7 @@ extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const 
                reinterpret_cast<uintptr_t>(kcache) | reinterpret_cast<uintptr_t>(vcache)) & 15) == 0);
   hipLaunchKernelGGL(attn_split_kernel, dim3(a.max_splits, H, B), dim3(AD_THREADS), 0, stream, a);
   int rc = eagle_check_launch();
-  if (rc || a.fused) return rc;
+  if (rc) return rc;
   hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B, (M + 1) / 2), dim3(2 * AD_MAXHD), 0, stream, a);
   return eagle_check_launch();
 }

@@ -51,39 +51,40 @@ __device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) 
 }
 
 // ---- stage 1, bf16: 32-bit keys ----
-// One wave's k candidates of wave chunk `wc` of row `xr` (64-bit keys: value | ~global index) into out[0..k).
-__device__ __forceinline__ void load_chunk_bf16(const bf16_t* __restrict__ xr, int V, int wc, int lane, bool vec_ok, uint4& a, uint4& b) {
-  const int base = wc * TK_WCHUNK + lane * TK_PER_LANE;
-  if (vec_ok && base + TK_PER_LANE <= V) {
-    a = *reinterpret_cast<const uint4*>(xr + base);
-    b = *reinterpret_cast<const uint4*>(xr + base + 8);
-  } else {
-    // ragged tail / unaligned rows: element loads, missing slots read as the bit pattern that keys to 0 below
-    uint32_t w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int i0 = base + 2 * i, i1 = i0 + 1;
-      w[i] = (i0 < V ? (uint32_t)xr[i0] : 0u) | ((i1 < V ? (uint32_t)xr[i1] : 0u) << 16);
-    }
-    a = make_uint4(w[0], w[1], w[2], w[3]);
-    b = make_uint4(w[4], w[5], w[6], w[7]);
-  }
-}
-template <typename OutPtr>
-__device__ __forceinline__ void select_chunk_bf16(const uint4 a, const uint4 b, int V, int wc, int lane, int k, OutPtr out) {
+__global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, int k,
+                                                                     int nwc, unsigned long long* __restrict__ cand,
+                                                                     const int64_t* __restrict__ block_index, int64_t block_rows) {
+  const int row = blockIdx.y;
+  if (block_index) x += *block_index * block_rows * ld;
+  const int lane = threadIdx.x & 63;
+  const int wc = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wc >= nwc) return;
+  const bf16_t* xr = x + (int64_t)row * ld;
   const int base = wc * TK_WCHUNK + lane * TK_PER_LANE;
   uint32_t key[TK_PER_LANE];
-  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  const bool vec = ((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (base + TK_PER_LANE <= V);
+  if (vec) {
+    const uint4 a = *reinterpret_cast<const uint4*>(xr + base);
+    const uint4 b = *reinterpret_cast<const uint4*>(xr + base + 8);
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    // invalid slots (beyond V) get key 0
-    key[2 * i] = base + 2 * i < V ? ((mono_bf16((bf16_t)(w[i] & 0xffff)) << 16) | (uint32_t)(TK_WCHUNK - 1 - (lane * TK_PER_LANE + 2 * i))) : 0u;
-    key[2 * i + 1] = base + 2 * i + 1 < V ? ((mono_bf16((bf16_t)(w[i] >> 16)) << 16) | (uint32_t)(TK_WCHUNK - 1 - (lane * TK_PER_LANE + 2 * i + 1))) : 0u;
+    for (int i = 0; i < 8; ++i) {
+      key[2 * i] = (mono_bf16((bf16_t)(w[i] & 0xffff)) << 16) | (uint32_t)(TK_WCHUNK - 1 - (lane * TK_PER_LANE + 2 * i));
+      key[2 * i + 1] = (mono_bf16((bf16_t)(w[i] >> 16)) << 16) | (uint32_t)(TK_WCHUNK - 1 - (lane * TK_PER_LANE + 2 * i + 1));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TK_PER_LANE; ++i) {
+      const int idx = base + i;
+      // invalid slots get key 0
+      key[i] = idx < V ? ((mono_bf16(xr[idx]) << 16) | (uint32_t)(TK_WCHUNK - 1 - (lane * TK_PER_LANE + i))) : 0u;
+    }
   }
   // valid keys are > 0: the smallest value part is 0x007f (-inf); NaN patterns map to 0xffff
   uint32_t best = 0;
 #pragma unroll
   for (int i = 0; i < TK_PER_LANE; ++i) best = key[i] > best ? key[i] : best;
+  unsigned long long* out = cand + ((int64_t)row * nwc + wc) * k;
   for (int r = 0; r < k; ++r) {
     const uint32_t bm = wave_umax(best);
     if (lane == 0) {
@@ -104,21 +105,6 @@ __device__ __forceinline__ void select_chunk_bf16(const uint4 a, const uint4 b, 
       }
     }
   }
-}
-
-__global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, int k,
-                                                                     int nwc, unsigned long long* __restrict__ cand,
-                                                                     const int64_t* __restrict__ block_index, int64_t block_rows) {
-  const int row = blockIdx.y;
-  if (block_index) x += *block_index * block_rows * ld;
-  const int lane = threadIdx.x & 63;
-  const int wc = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wc >= nwc) return;
-  const bf16_t* xr = x + (int64_t)row * ld;
-  const bool vec = ((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  uint4 a, b;
-  load_chunk_bf16(xr, V, wc, lane, vec, a, b);
-  select_chunk_bf16(a, b, V, wc, lane, k, cand + ((int64_t)row * nwc + wc) * k);
 }
 
 // ---- stage 1, fp32: 64-bit keys ----
@@ -156,33 +142,32 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_f32_kernel(const float
   }
 }
 
-// Merge `ncand` 64-bit candidate keys of one row (global or LDS) into its k winners: threads 0..255 of the
-// workgroup take part (4 waves); every thread of the workgroup must reach the call (one barrier inside).
-template <typename T, typename CandPtr>
-__device__ __forceinline__ void merge_candidates(CandPtr cand, int ncand, int k, const T* __restrict__ xrow,
-                                                 int64_t* __restrict__ out_idx, T* __restrict__ out_val,
-                                                 unsigned long long* surv) {
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  if (wave < 4) {
-    unsigned long long key[TK_CM];
+template <typename T>
+__global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
+                                                                const T* __restrict__ x, int64_t ld,
+                                                                int64_t* __restrict__ out_idx, T* __restrict__ out_val,
+                                                                const int64_t* __restrict__ block_index, int64_t block_rows) {
+  __shared__ unsigned long long surv[4 * TK_MAXK];
+  if (block_index) x += *block_index * block_rows * ld;
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned long long key[TK_CM];
 #pragma unroll
-    for (int i = 0; i < TK_CM; ++i) {
-      const int c = t + i * TK_THREADS;
-      key[i] = c < ncand ? cand[c] : 0ull;
-    }
-    unsigned long long best = 0;
+  for (int i = 0; i < TK_CM; ++i) {
+    const int c = t + i * TK_THREADS;
+    key[i] = c < ncand ? cand[(int64_t)row * ncand + c] : 0ull;
+  }
+  unsigned long long best = 0;
 #pragma unroll
-    for (int i = 0; i < TK_CM; ++i) best = key[i] > best ? key[i] : best;
-    for (int r = 0; r < k; ++r) {
-      const unsigned long long bm = wave_umax64(best);
-      if (lane == 0) surv[wave * TK_MAXK + r] = bm;
-      if (bm != 0 && best == bm) {
-        best = 0;
+  for (int i = 0; i < TK_CM; ++i) best = key[i] > best ? key[i] : best;
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long bm = wave_umax64(best);
+    if (lane == 0) surv[wave * TK_MAXK + r] = bm;
+    if (bm != 0 && best == bm) {
+      best = 0;
 #pragma unroll
-        for (int i = 0; i < TK_CM; ++i) {
-          if (key[i] == bm) key[i] = 0;
-          best = key[i] > best ? key[i] : best;
-        }
+      for (int i = 0; i < TK_CM; ++i) {
+        if (key[i] == bm) key[i] = 0;
+        best = key[i] > best ? key[i] : best;
       }
     }
   }
@@ -199,58 +184,15 @@ __device__ __forceinline__ void merge_candidates(CandPtr cand, int ncand, int k,
   if (lane < k) {
     // fewer than k entries can only happen when V < k; emit index -1 then
     const int64_t idx = won ? (int64_t)(0xffffffffu - (uint32_t)(won & 0xffffffffu)) : -1;
-    out_idx[lane] = idx;
-    if (out_val) out_val[lane] = idx >= 0 ? xrow[idx] : (T)0;
+    out_idx[(int64_t)row * k + lane] = idx;
+    if (out_val) out_val[(int64_t)row * k + lane] = idx >= 0 ? x[(int64_t)row * ld + idx] : (T)0;
   }
-}
-
-template <typename T>
-__global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
-                                                                const T* __restrict__ x, int64_t ld,
-                                                                int64_t* __restrict__ out_idx, T* __restrict__ out_val,
-                                                                const int64_t* __restrict__ block_index, int64_t block_rows) {
-  __shared__ unsigned long long surv[4 * TK_MAXK];
-  if (block_index) x += *block_index * block_rows * ld;
-  const int row = blockIdx.x;
-  merge_candidates<T>(cand + (int64_t)row * ncand, ncand, k, x + (int64_t)row * ld, out_idx + (int64_t)row * k,
-                      out_val ? out_val + (int64_t)row * k : (T*)nullptr, surv);
-}
-
-// ---- one launch, bf16: one workgroup of 16 waves per row; the candidates go through LDS ----
-// Each wave selects from the wave chunks wave, wave + 16, ... (the next chunk's loads are issued before the current
-// chunk's k rounds), then four waves merge as in stage 2.  Used when a row has few chunks per wave or when there
-// are enough rows to fill the chip; otherwise the two-stage form spreads one row's scan over more CUs.
-#define TK_FUSED_THREADS 1024
-__global__ __launch_bounds__(TK_FUSED_THREADS) void topk_fused_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, int k, int nwc,
-                                                                          int64_t* __restrict__ out_idx, bf16_t* __restrict__ out_val,
-                                                                          const int64_t* __restrict__ block_index, int64_t block_rows) {
-  __shared__ unsigned long long cand[TK_THREADS * TK_CM];
-  __shared__ unsigned long long surv[4 * TK_MAXK];
-  if (block_index) x += *block_index * block_rows * ld;
-  const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bf16_t* xr = x + (int64_t)row * ld;
-  const bool vec = ((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  uint4 a, b, na, nb;
-  int wc = wave;
-  if (wc < nwc) load_chunk_bf16(xr, V, wc, lane, vec, a, b);
-  for (; wc < nwc; wc += TK_FUSED_THREADS / 64) {
-    const int nxt = wc + TK_FUSED_THREADS / 64;
-    if (nxt < nwc) load_chunk_bf16(xr, V, nxt, lane, vec, na, nb);
-    select_chunk_bf16(a, b, V, wc, lane, k, cand + wc * k);
-    a = na; b = nb;
-  }
-  __syncthreads();
-  merge_candidates<bf16_t>(cand, nwc * k, k, xr, out_idx + (int64_t)row * k, out_val ? out_val + (int64_t)row * k : (bf16_t*)nullptr, surv);
 }
 
 extern "C" int64_t eagle_topk_workspace_bytes(int rows, int V, int k) {
   const int64_t nwc = (V + TK_WCHUNK - 1) / TK_WCHUNK;
   return (int64_t)rows * nwc * k * 8;
 }
-
-static int g_topk_fused = 1;
-// debug / test switch: 0 forces the two-launch form for bf16 logits
-extern "C" void eagle_debug_set_topk_fused(int on) { g_topk_fused = on; }
 
 // dtype: 0 = bf16 logits, 1 = fp32 logits
 extern "C" int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V, int k,
@@ -263,10 +205,7 @@ extern "C" int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int r
   if ((int64_t)nwc * k > TK_THREADS * TK_CM) return EAGLE_ERR_SHAPE;
   unsigned long long* cand = (unsigned long long*)workspace;
   dim3 g1((nwc + 3) / 4, rows);
-  if (dtype == 0 && g_topk_fused && (nwc <= 4 * (TK_FUSED_THREADS / 64) || rows >= 128)) {
-    hipLaunchKernelGGL(topk_fused_bf16_kernel, dim3(rows), dim3(TK_FUSED_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc,
-                       out_idx, (bf16_t*)out_val, block_index, block_rows);
-  } else if (dtype == 0) {
+  if (dtype == 0) {
     hipLaunchKernelGGL(topk_stage1_bf16_kernel, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand, block_index, block_rows);
     hipLaunchKernelGGL(topk_stage2_kernel<bf16_t>, dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                        (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows);

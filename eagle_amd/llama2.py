@@ -222,9 +222,7 @@ class Llama2Model(nn.Module):
         need = ops.query("eagle_attn_decode_workspace_bytes", B, H, max_kv)
         ws = getattr(self, "_attn_ws", None)
         if ws is None or ws.numel() < need or ws.device != dev:
-            # zeroed: the head of the workspace holds the arrival tickets of the split-KV merge, which every call
-            # expects at zero and leaves at zero (include/eagle_hip.h, eagle_tree_attention_bf16)
-            ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
             self._attn_ws = ws
         return ws
 

@@ -101,11 +101,7 @@ int eagle_rmsnorm_bwd_bf16(const void* dy, const void* x, const void* w, const f
  * key columns (tree_mask_batch_stride 0 = shared by all requests); pad_mask [B, >= past+M] bytes
  * (0 = padded key) or NULL; causal != 0 adds the causal mask when M > 1.  out [B*rows_per_req, H*hd].
  * max_kv >= max_b(past+M) sizes the grid and the workspace
- * (eagle_attn_decode_workspace_bytes(B, H, max_kv) bytes: 64 KB of arrival tickets, one int per
- * (request, head), then the fp32 partials).  The ticket bytes must be ZERO before the first call on a
- * workspace; every call leaves them zero, so calls that follow each other on one stream need no
- * clearing, and calls that overlap on one workspace race.  The split-KV partials are merged by the
- * workgroup that draws the last ticket of its (request, head): one launch.
+ * (eagle_attn_decode_workspace_bytes(B, H, max_kv) bytes of fp32 partials).
  * Device-side violations (past+M > cap or > max_kv) set *err_flag = 1 and skip the request.
  * Replaces LlamaAttention.forward after the projections, eagle/llama2.py:226-273, with the mask
  * semantics of _prepare_decoder_attention_mask :460-491 (tree overlay :482-488). */

@@ -147,27 +147,6 @@ def test_topk_bit_exact(rows, V, dtype):
     assert torch.equal(ops.first_argmax(x.to(dev())).cpu(), ot.first_argmax(x))
 
 
-@pytest.mark.parametrize("rows,V,fused", [(130, 151936, 1), (2, 32000, 0), (5, 20000, 0), (3, 70000, 1), (130, 1000, 1)])
-def test_topk_one_launch_and_two_launch_forms(rows, V, fused):
-    """bf16 top-k takes one launch (a 16-wave workgroup per row, candidates through LDS) for few chunks per wave or
-    many rows, else two launches; both forms against the stable-sort oracle, each forced where the other is the default."""
-    import ctypes
-    from eagle_amd import _hip, ops
-    sw = _hip.lib().eagle_debug_set_topk_fused
-    sw.argtypes, sw.restype = [ctypes.c_int], None
-    g = torch.Generator().manual_seed(rows + V)
-    x = (torch.randn(rows, V, generator=g) * 4).to(BF)
-    ev, ei = ot.stable_topk(x, 10)
-    try:
-        sw(fused)
-        v, i = ops.topk(x.to(dev()), 10)
-        torch.cuda.synchronize()
-    finally:
-        sw(1)
-    assert torch.equal(i.cpu(), ei)
-    assert torch.equal(v.cpu(), ev)
-
-
 def test_topk_tie_and_special_values():
     from eagle_amd import ops
     x = torch.zeros(4, 5000, dtype=BF)
@@ -256,41 +235,6 @@ def test_model_long_prefill_and_decode_vs_oracle():
         ro1, _ = dm.forward(wb, dims, h1, i1, past_key_values=rkv, use_cache=True)
         o1, _ = m(h1.to(d), i1.to(d), past_key_values=kv, use_cache=True)
         close(o1, ro1, what="decode out")
-
-
-@pytest.mark.parametrize("fused", [1, 0])
-def test_split_kv_attention_merge_forms(fused):
-    """Split-KV attention over many 64-key chunks (prompt of 333 tokens -> 6 chunks per head), merged by the last
-    arriving workgroup in the same launch (default) or by the second launch: both against the oracle, several decode
-    steps in a row so that the arrival tickets are reused."""
-    import ctypes
-    from eagle_amd import _hip
-    sw = _hip.lib().eagle_debug_set_attn_fused
-    sw.argtypes, sw.restype = [ctypes.c_int], None
-    dims = dm.DraftDims(hidden=512, inter=256, heads=4, kv_heads=2, vocab=300)  # head_dim 128, grouped kv heads
-    w = dm.init_weights(dims, seed=11, std=0.05)
-    m = _model(dims, w)
-    wb = {k: v.to(BF) for k, v in w.items()}
-    g = torch.Generator().manual_seed(21)
-    h = torch.randn(2, 333, 512, generator=g).to(BF)
-    ids = torch.randint(0, 300, (2, 333), generator=g)
-    d = dev()
-    try:
-        sw(fused)
-        with torch.no_grad():
-            ro, rkv = dm.forward(wb, dims, h, ids, use_cache=True)
-            o, kv = m(h.to(d), ids.to(d), use_cache=True)
-            close(o, ro, what="prefill out")
-            for step in range(4):
-                q = 1 + 3 * step
-                h1 = torch.randn(2, q, 512, generator=g).to(BF)
-                i1 = torch.randint(0, 300, (2, q), generator=g)
-                ro1, rkv = dm.forward(wb, dims, h1, i1, past_key_values=rkv, use_cache=True)
-                o1, kv = m(h1.to(d), i1.to(d), past_key_values=kv, use_cache=True)
-                close(o1, ro1, what="decode step %d" % step)
-        torch.cuda.synchronize()
-    finally:
-        sw(1)
 
 
 # ------------------------------------------------------------------ tree kernels (bit-exact)
