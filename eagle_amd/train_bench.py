@@ -11,6 +11,8 @@ loss-masked tokens per step / step wall time, summed over ranks.
 """
 from __future__ import annotations
 
+import json
+import os
 import time
 from typing import Optional
 
@@ -53,8 +55,18 @@ def loss_roofline(dev, N: int, V: int, D: int, iters: int = 8) -> dict:
     t_f, t_b = ev[0].elapsed_time(ev[1]) / iters * 1e-3, ev[1].elapsed_time(ev[2]) / iters * 1e-3
     b_f, b_b = 2.0 * N * V * 2 + 2.0 * N * D * 2, 3.0 * N * V * 2 + 3.0 * N * D * 2
     ach = (b_f + b_b) / (t_f + t_b) / 1e9
+    # HBM bytes of one forward + one backward from rocprofv3 PMC passes of the same kernels at this shape
+    # (profiles/r01_loss_pmc.json: tools/gpu_profile2.sh + tools/pmc2_to_json.py), else null
+    traffic = None
+    pj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_loss_pmc.json")
+    if os.path.exists(pj):
+        with open(pj) as f:
+            pm = json.load(f)
+        if pm.get("shape") == {"N": N, "V": V, "D": D}:
+            traffic = pm.get("traffic_bytes_fwd_plus_bwd")
     return {"bound": "hbm", "kernel": "ce_partial_kernel + ce_combine_kernel (fwd), ce_bwd_kernel (bwd)", "achieved": ach,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "bytes_fwd_plus_bwd": b_f + b_b,
             "fwd": {"us": t_f * 1e6, "bytes": b_f, "GB/s": b_f / t_f / 1e9}, "bwd": {"us": t_b * 1e6, "bytes": b_b, "GB/s": b_b / t_b / 1e9},
             "shape": {"N": N, "V": V, "D": D}, "timing": "HIP events around %d back-to-back launches each" % iters}
 
