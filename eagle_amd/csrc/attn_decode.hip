@@ -8,7 +8,7 @@
 // transpose back to [B, q, H*hd] (:272-273).
 //
 // Split-KV ("flash-decoding") layout so that a batch-1 request still fills the chip:
-//   kernel 1: one workgroup per (64-key chunk, head, request) -- or, for wide ragged batches, per stride of chunks.  K rows stream HBM/L2 -> VGPR as
+//   kernel 1: one workgroup per (64-key chunk, head, request).  K rows stream HBM/L2 -> VGPR as
 //             MFMA A fragments (v_mfma_f32_16x16x32_bf16: keys x queries), chunk-local softmax
 //             in fp32, P.V on the VALU with every V load of the chunk in flight at once;
 //             writes (m, l, O~) partials.
@@ -42,22 +42,14 @@ struct AttnDecArgs {
 
 // workspace record per (b, h, split): [AD_MAXM][AD_MAXHD] fp32 O~  then [AD_MAXM][2] fp32 (m, l)
 #define AD_REC (AD_MAXM * AD_MAXHD + AD_MAXM * 2)
-// dynamic LDS of attn_split_kernel for M query rows: q_s + (rowm, rowl) + M rows of knew, vnew, P and 4 x red
-#define AD_LDS_BYTES(M) (AD_MAXM * AD_MAXHD * 2 + 2 * AD_MAXM * 4 + (M) * (2 * AD_MAXHD * 2 + AD_CH * 4 + 4 * AD_MAXHD * 4))
 
 __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
-  // LDS sized by the call's row count M (dynamic allocation, AD_LDS_BYTES(M)): q_s keeps all 16 MFMA columns (rows >= M
-  // zero), everything else has M rows -- a 4-row tree step takes 15 KB instead of 48 KB, so 8 workgroups instead of 3
-  // share a CU and the per-workgroup latency chain of a wide ragged batch overlaps that much more
-  extern __shared__ __attribute__((aligned(16))) unsigned char ad_lds[];
-  bf16_t* q_s = reinterpret_cast<bf16_t*>(ad_lds);                                     // [AD_MAXM][AD_MAXHD]
-  float* rowm = reinterpret_cast<float*>(ad_lds + AD_MAXM * AD_MAXHD * 2);             // [AD_MAXM]
-  float* rowl = rowm + AD_MAXM;                                                        // [AD_MAXM]
-  unsigned char* dyn = ad_lds + AD_MAXM * AD_MAXHD * 2 + 2 * AD_MAXM * 4;
-  bf16_t* knew = reinterpret_cast<bf16_t*>(dyn);                                       // [M][AD_MAXHD]
-  bf16_t* vnew = knew + p.M * AD_MAXHD;                                                // [M][AD_MAXHD]
-  float* P = reinterpret_cast<float*>(vnew + p.M * AD_MAXHD);                          // [M][AD_CH]
-  float* red = P + p.M * AD_CH;                                                        // [4][M][AD_MAXHD]
+  __shared__ __attribute__((aligned(16))) bf16_t q_s[AD_MAXM * AD_MAXHD];
+  __shared__ __attribute__((aligned(16))) bf16_t knew[AD_MAXM * AD_MAXHD];
+  __shared__ __attribute__((aligned(16))) bf16_t vnew[AD_MAXM * AD_MAXHD];
+  __shared__ __attribute__((aligned(16))) float P[AD_MAXM * AD_CH];
+  __shared__ __attribute__((aligned(16))) float red[4][AD_MAXM][AD_MAXHD];
+  __shared__ float rowm[AD_MAXM], rowl[AD_MAXM];
 
   const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hd = p.hd, M = p.M;
@@ -69,31 +61,19 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
     if (t == 0 && split == 0 && p.err_flag) atomicExch(p.err_flag, 1);
     return;
   }
-  // this workgroup takes the 64-key chunks split, split + gridDim.x, ... of its (head, request): with ragged batches
-  // most requests are far shorter than max_kv, and a grid of max_splits chunks per request would mostly dispatch
-  // workgroups that exit at once (batch 32, cap 2048: 36,864 workgroups for ~6,000 chunks)
-  const int nsplit = gridDim.x;
-  if (split * AD_CH >= total) return;
+  const int c_begin = split * AD_CH;
+  if (c_begin >= total) return;
+  const int c_end = (c_begin + AD_CH < total) ? c_begin + AD_CH : total;
   bf16_t* kc = p.kcache + (int64_t)b * p.c_bstride + (int64_t)hk * p.c_hstride;
   bf16_t* vc = p.vcache + (int64_t)b * p.c_bstride + (int64_t)hk * p.c_hstride;
   const int half = hd >> 1;
-  const int ns_all = (total + AD_CH - 1) / AD_CH;
-  const int my_last = split + ((ns_all - 1 - split) / nsplit) * nsplit;            // last chunk of this workgroup
-  const bool stage_new = ((my_last + 1) * AD_CH > past);                            // one of its chunks holds rows appended by this call
+  const bool need_new = c_end > past;           // this chunk contains rows appended by this call
   const bool writer = (split == 0) && (h % rep == 0);
-  const int r16 = lane & 15, g = lane >> 4;
-  const int ksteps = (hd + 31) >> 5;
-  const int dpn = half;                          // d pairs
-  const int dp = t % dpn, kg = t / dpn;          // hd=128: 64 pairs x 4 key groups
-  const int ngroups = AD_THREADS / dpn;          // >= 4
-  const int kpg = AD_CH / ngroups;               // keys per group: 16 for hd=128, fewer below
-
-  for (int chunk = split; chunk * AD_CH < total; chunk += nsplit) {
-  const int c_begin = chunk * AD_CH;
-  const int c_end = (c_begin + AD_CH < total) ? c_begin + AD_CH : total;
 
   // ---- early loads: cached K fragments and V pairs do not depend on this call's RoPE, so they
   //      are issued first and their latency overlaps phases 0-2 ----
+  const int r16 = lane & 15, g = lane >> 4;
+  const int ksteps = (hd + 31) >> 5;
   const int kc0 = c_begin + wave * 16;           // first key of this wave's MFMA tile
   const int kcl = kc0 + r16;                     // this lane's key
   bf16x8 kf[AD_MAXHD / 32];
@@ -104,6 +84,10 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
     kf[s] = (s < ksteps && d0 < hd && kcl < c_end && kcl < past)
                 ? *reinterpret_cast<const bf16x8*>(kc + (int64_t)kcl * hd + d0) : z;
   }
+  const int dpn = half;                          // d pairs
+  const int dp = t % dpn, kg = t / dpn;          // hd=128: 64 pairs x 4 key groups
+  const int ngroups = AD_THREADS / dpn;          // >= 4
+  const int kpg = AD_CH / ngroups;               // keys per group: 16 for hd=128, fewer below
   uint32_t vv[16];
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
@@ -111,7 +95,6 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
     vv[u] = (u < kpg && c < c_end && c < past) ? *reinterpret_cast<const uint32_t*>(vc + (int64_t)c * hd + 2 * dp) : 0u;
   }
 
-  if (chunk == split) {
   // ---- phase 0: RoPE on q (always) and on the new k rows (if needed); append to the cache ----
   if (p.vec16) {
     // 8 elements (16 bytes) per thread: with hd = 128 the 16 rows x 16 chunks are one item per thread,
@@ -127,7 +110,7 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
         const bool lo = d0 < half;
         const int dp0 = lo ? d0 + half : d0 - half;
         const bf16_t* qrow = p.qkv + row * p.ld_qkv + h * hd;
-        const bool kv_too = stage_new || writer;
+        const bool kv_too = need_new || writer;
         const bf16_t* krow = p.qkv + row * p.ld_qkv + (p.H + hk) * hd;
         const bf16_t* vrow = p.qkv + row * p.ld_qkv + (p.H + p.HK + hk) * hd;
         const uint4 cv = *reinterpret_cast<const uint4*>(p.cos_t + ps * hd + d0);
@@ -183,7 +166,7 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
       float qv = bf2f(qrow[d]), qr = bf2f(qrow[dp]);
       if (d < half) qr = -qr;
       q_s[m * AD_MAXHD + d] = f2bf(rbf(qv * c) + rbf(qr * s));
-      if (stage_new || writer) {
+      if (need_new || writer) {
         const bf16_t* krow = p.qkv + row * p.ld_qkv + (p.H + hk) * hd;
         const bf16_t* vrow = p.qkv + row * p.ld_qkv + (p.H + p.HK + hk) * hd;
         float kv = bf2f(krow[d]), kr = bf2f(krow[dp]);
@@ -201,8 +184,7 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
       q_s[m * AD_MAXHD + d] = 0;
     }
   }
-  }  // first chunk: phase 0
-  __syncthreads();   // q_s / knew / vnew staged; the previous chunk's reads of P, red, rowm, rowl are done
+  __syncthreads();
 
   // ---- phase 1: scores for 16 keys per wave on MFMA; mask; fp32 into P ----
   {
@@ -236,15 +218,14 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
       if (tm && vis && cc >= tree0) vis = tm[m * p.T + (cc - tree0)] != 0;
       sc[r] = vis ? rbf(rbf(acc[r]) / p.sqrt_hd) : -INFINITY;
     }
-    if (m < M) *reinterpret_cast<float4*>(&P[m * AD_CH + wave * 16 + 4 * g]) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+    *reinterpret_cast<float4*>(&P[m * AD_CH + wave * 16 + 4 * g]) = make_float4(sc[0], sc[1], sc[2], sc[3]);
   }
   __syncthreads();
 
   // ---- phase 2: chunk-local softmax numerators: 16 threads per row, 4 keys each ----
   {
     const int m = t >> 4, j = t & 15;
-    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    if (m < M) v = *reinterpret_cast<const float4*>(&P[m * AD_CH + 4 * j]);
+    float4 v = *reinterpret_cast<const float4*>(&P[m * AD_CH + 4 * j]);
     float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
@@ -255,7 +236,7 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
     float sum = e.x + e.y + e.z + e.w;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-    if (m < M) *reinterpret_cast<float4*>(&P[m * AD_CH + 4 * j]) = e;
+    *reinterpret_cast<float4*>(&P[m * AD_CH + 4 * j]) = e;
     if (j == 0) { rowm[m] = mx; rowl[m] = sum; }
   }
   __syncthreads();
@@ -303,7 +284,7 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
 #pragma unroll
         for (int m = 0; m < AD_MAXM; ++m) {
           if (m < M) {
-            float* r = &red[(slot * M + m) * AD_MAXHD + 2 * dp];
+            float* r = &red[slot][m][2 * dp];
             if (pass == 0) { r[0] = a0[m]; r[1] = a1[m]; } else { r[0] += a0[m]; r[1] += a1[m]; }
           }
         }
@@ -311,16 +292,15 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
       __syncthreads();
     }
     const int ng4 = ngroups < 4 ? ngroups : 4;
-    float* rec = p.ws + ((int64_t)(b * p.H + h) * p.max_splits + chunk) * AD_REC;
+    float* rec = p.ws + ((int64_t)(b * p.H + h) * p.max_splits + split) * AD_REC;
     for (int i = t; i < M * hd; i += AD_THREADS) {
       const int m = i / hd, d = i - m * hd;
       float s = 0.f;
-      for (int q = 0; q < ng4; ++q) s += red[(q * M + m) * AD_MAXHD + d];
+      for (int q = 0; q < ng4; ++q) s += red[q][m][d];
       rec[m * AD_MAXHD + d] = s;
     }
     if (t < M) { rec[AD_MAXM * AD_MAXHD + 2 * t] = rowm[t]; rec[AD_MAXM * AD_MAXHD + 2 * t + 1] = rowl[t]; }
   }
-  }  // chunk loop
 }
 
 // grid (H, B, ceil(M/2)); 256 threads = 2 rows x 128 d.  All partial loads of a row are issued
@@ -370,10 +350,6 @@ extern "C" int64_t eagle_attn_decode_workspace_bytes(int B, int H, int max_kv) {
   return (int64_t)B * H * ((max_kv + AD_CH - 1) / AD_CH) * AD_REC * sizeof(float);
 }
 
-static int g_attn_splits = 0;
-// debug / test switch: force the number of chunk strides per (head, request); 0 = sized from B * H
-extern "C" void eagle_debug_set_attn_splits(int n) { g_attn_splits = n; }
-
 // See include/eagle_hip.h for the contract.
 extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const int64_t* position_ids, int pos_off,
                                          int pos_stride, const void* cos_table, const void* sin_table, int n_pos,
@@ -405,13 +381,7 @@ extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const 
   a.vec16 = ((hd & 15) == 0) && ((cache_batch_stride & 7) == 0) &&
             (((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(cos_table) | reinterpret_cast<uintptr_t>(sin_table) |
                reinterpret_cast<uintptr_t>(kcache) | reinterpret_cast<uintptr_t>(vcache)) & 15) == 0);
-  // chunks per (head, request) in the grid: all of them while that keeps the grid small (batch 1: every chunk its own
-  // workgroup), else about 8192 workgroups in all, each looping over its chunks (at least 4 per (head, request))
-  int nsplit = 8192 / (B * H);
-  nsplit = nsplit < 4 ? 4 : nsplit;
-  if (g_attn_splits > 0) nsplit = g_attn_splits;
-  nsplit = nsplit > a.max_splits ? a.max_splits : nsplit;
-  hipLaunchKernelGGL(attn_split_kernel, dim3(nsplit, H, B), dim3(AD_THREADS), AD_LDS_BYTES(M), stream, a);
+  hipLaunchKernelGGL(attn_split_kernel, dim3(a.max_splits, H, B), dim3(AD_THREADS), 0, stream, a);
   int rc = eagle_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B, (M + 1) / 2), dim3(2 * AD_MAXHD), 0, stream, a);

@@ -91,11 +91,7 @@ __device__ __forceinline__ void g8_stage(const G8Src& s, int h, int kt, bf16_t* 
   }
 }
 
-// ROWSKIP (decode batches of 65..192 rows against big weights: one row tile, mostly padding): a wave multiplies only
-// the 16-row blocks of its 128-row half that hold valid rows and reads only their fragments; the DMA, the barriers and
-// the vmcnt arithmetic are those of the full tile.  With M <= 128 the wr = 1 waves only stage, and each SIMD runs one
-// multiplying wave: the tile costs half the MFMA time, which is what bounds these weight-streaming launches.
-template <bool PINGPONG, int DBG = 0, bool ROWSKIP = false>
+template <bool PINGPONG, int DBG = 0>
 __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   // ONE shared array (a second LDS object makes hipcc drain the DMA before every ds_read):
   // [buffer 2][A0, A1, B0, B1][128 x 64]  = 128 KB
@@ -141,7 +137,6 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  const int vrows = ROWSKIP ? p.M - m0 - wr * 128 : 128;    // valid rows of this wave's half (<= 0: nothing to multiply)
   bf16x8 af[4][2], bf0[2][2], bf1[2][2];     // A: 4 m-tiles x 2 k-steps; B quadrant nh: 2 n-tiles x 2 k-steps
   const int a_row0 = r16;                                  // + mh*64 + i*16 within the wave's A half
   const int b_row0 = (wc & 1) * 64 + r16;                  // + nh*32 + j*16 within the wave's B half
@@ -149,14 +144,12 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = a_row0 + mh * 64 + i * 16;
-      if (ROWSKIP && vrows <= mh * 64 + i * 16) continue;
 #pragma unroll
       for (int s = 0; s < 2; ++s)
         af[i][s] = *reinterpret_cast<const bf16x8*>(la + row * G8_BK + (((4 * s + g) ^ (row & 7)) << 3));
     }
   };
   auto read_b = [&](const bf16_t* lb, int nh, bf16x8 (&bf)[2][2]) {
-    if (ROWSKIP && vrows <= 0) return;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = b_row0 + nh * 32 + j * 16;
@@ -171,7 +164,6 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                       \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                       \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                       \
-    if (!ROWSKIP || vrows > (MH) * 64 + i * 16)                                                       \
     acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[j][s], af[i][s], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(G8_PRIO_R);
 
@@ -426,9 +418,6 @@ extern "C" void eagle_debug_set_gemm8_gm(int gm) { g_g8_gm = gm; }
 static int g_g8_pingpong = -1;     // EAGLE_GEMM8_PINGPONG=0 selects the in-phase schedule (A/B measurements)
 extern "C" void eagle_debug_set_gemm8_pingpong(int on) { g_g8_pingpong = on; }
 
-static int g_g8_rowskip = 1;       // 0: the full-tile kernel also for a single, mostly padded row tile (A/B measurements, tests)
-extern "C" void eagle_debug_set_gemm8_rowskip(int on) { g_g8_rowskip = on; }
-
 // Called by eagle_gemm_nt_bf16 (gemm_mfma.hip) after its argument checks.
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                           const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
@@ -462,9 +451,7 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
       case 64: hipLaunchKernelGGL((gemm_nt8_kernel<true, 64>), gr, bl, 0, stream, a); break;
       default: return EAGLE_ERR_ARG;
     }
-  } else if (g_g8_pingpong && g_g8_rowskip && a.tiles_m == 1 && M <= 240)
-    hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, true>), dim3(a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
-  else if (g_g8_pingpong) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
+  } else if (g_g8_pingpong) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
   else hipLaunchKernelGGL(gemm_nt8_kernel<false>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
   int rc = eagle_check_launch();
   if (rc || a.ksplit == 1) return rc;
