@@ -237,6 +237,48 @@ def test_model_long_prefill_and_decode_vs_oracle():
         close(o1, ro1, what="decode out")
 
 
+def test_split_kv_attention_chunk_strides():
+    """Wide ragged batches give each attention workgroup a stride of 64-key chunks instead of one chunk; forced here
+    on a small model (333-token prompts = 6 chunks over 2 strides): against the oracle, and bit-identical to the
+    one-chunk-per-workgroup grid, over a prefill and several decode steps."""
+    import ctypes
+    from eagle_amd import _hip
+    sw = _hip.lib().eagle_debug_set_attn_splits
+    sw.argtypes, sw.restype = [ctypes.c_int], None
+    dims = dm.DraftDims(hidden=512, inter=256, heads=4, kv_heads=2, vocab=300)  # head_dim 128, grouped kv heads
+    w = dm.init_weights(dims, seed=11, std=0.05)
+    wb = {k: v.to(BF) for k, v in w.items()}
+    d = dev()
+    outs = {}
+    try:
+        for forced in (0, 2, 1):
+            sw(forced)
+            m = _model(dims, w)
+            g = torch.Generator().manual_seed(21)
+            h = torch.randn(2, 333, 512, generator=g).to(BF)
+            ids = torch.randint(0, 300, (2, 333), generator=g)
+            got = []
+            with torch.no_grad():
+                ro, rkv = dm.forward(wb, dims, h, ids, use_cache=True)
+                o, kv = m(h.to(d), ids.to(d), use_cache=True)
+                close(o, ro, what="prefill out")
+                got.append(o.cpu())
+                for step in range(3):
+                    q = 1 + 3 * step
+                    h1 = torch.randn(2, q, 512, generator=g).to(BF)
+                    i1 = torch.randint(0, 300, (2, q), generator=g)
+                    ro1, rkv = dm.forward(wb, dims, h1, i1, past_key_values=rkv, use_cache=True)
+                    o1, kv = m(h1.to(d), i1.to(d), past_key_values=kv, use_cache=True)
+                    close(o1, ro1, what="decode step %d" % step)
+                    got.append(o1.cpu())
+            outs[forced] = got
+    finally:
+        sw(0)
+    for forced in (2, 1):
+        for a, b in zip(outs[0], outs[forced]):
+            assert torch.equal(a, b), "chunk-stride grid differs from the one-chunk-per-workgroup grid"
+
+
 # ------------------------------------------------------------------ tree kernels (bit-exact)
 def test_greedy_accept_and_compaction_bit_exact():
     from eagle_amd import ops
@@ -478,7 +520,9 @@ def test_gemm_nt(M, N, K):
     close(ya, acc + ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="gemm_nt accumulate fp32")
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 4096), (300, 515, 192), (2048, 1024, 512), (1, 9, 128), (257, 255, 64 * 7)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 4096), (300, 515, 192), (2048, 1024, 512), (1, 9, 128), (257, 255, 64 * 7),
+                                   # one mostly padded row tile: the row-skipping instantiation (decode batches)
+                                   (128, 512, 256), (96, 300, 192), (192, 1024, 512), (33, 256, 128), (65, 515, 64 * 5), (240, 256, 64)])
 def test_gemm_nt_256_tile_kernel(M, N, K):
     """The 256x256 kernel (DMA in flight across barriers) forced on every shape, against fp32 torch
     and bit-for-bit-close to the 128x128 kernel's contract: ragged M/N, bias, residual, fp32, accumulate."""
@@ -526,7 +570,8 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
         setm(2)
 
 
-@pytest.mark.parametrize("M,N,K,S", [(256, 256, 1024, 4), (300, 130, 64 * 37, 5), (2048, 512, 8192, 4), (64, 64, 128, 8)])
+@pytest.mark.parametrize("M,N,K,S", [(256, 256, 1024, 4), (300, 130, 64 * 37, 5), (2048, 512, 8192, 4), (64, 64, 128, 8),
+                                     (128, 512, 2048, 4), (48, 300, 64 * 9, 3), (192, 4096, 4096, 16)])
 def test_gemm_nt_split_k(M, N, K, S):
     """Split-K form (the lm_head dgrad shape: few output tiles, long K) against fp32 torch and the
     single-pass kernel; bias / residual / fp32 epilogues go through the reduce kernel."""
