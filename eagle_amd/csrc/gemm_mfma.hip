@@ -161,6 +161,10 @@ static bool use_gemm8(int M, int N, int K) {
   if (g_gemm8_mode < 0) { const char* e = getenv("EAGLE_GEMM8"); g_gemm8_mode = e ? atoi(e) : 2; }
   if (g_gemm8_mode == 0 || K < 2 * GM_BK) return false;
   if (g_gemm8_mode == 1) return true;
+  // decode batches (a row tile that is mostly padding) stream the weights once whatever the tile: the 128x128
+  // kernel's two workgroups per CU and finer tail win there (lm_head 151936 x 4096 at 128 rows: 345 vs 540 us,
+  // at 32 rows 304 vs 449 us; tools/lm_head_bench.py)
+  if (M <= 192) return false;
   const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
   return t256 >= 256;            // at least one full round of 256x256 tiles over the 256 CUs (measured: tools/gemm_bench.py)
 }

@@ -57,6 +57,7 @@ class EagleDrafter:
         self.R = 1 + self.n_fwd                              # flat top-k rows per request
         self.cap = (max_ctx + self.W + self.n_fwd + 255) // 256 * 256
         self.dev, self.D = dev, model.config.hidden_size
+        self.wide_head_rows = 32      # lm_head row blocks from this many rows on take the MFMA GEMM (one weight pass)
         # static bound on stable_len + tree rows handed to the attention launcher (grid size); a caller
         # that knows a tighter bound for the coming cycles may lower it (must stay >= the true length)
         self.kv_bound = self.cap
@@ -98,8 +99,10 @@ class EagleDrafter:
     # -------------------------------------------------------------- draft side
     def _head_topk(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int, row0: int, n: int):
         """top-k(lm_head(x[idx])) -> flat rows [row0, row0+n) of every request."""
-        if idx is None and rows > 64 and self.D % 64 == 0:
-            logits = ops.gemm_nt(x, self.lm_head)            # wide batches: one weight pass on the MFMA GEMM
+        if rows >= self.wide_head_rows and self.D % 64 == 0:
+            # wide batches: one weight pass on the MFMA GEMM (from 32 rows on it beats the weight-stream kernel, which
+            # passes over the weights once per 32 rows: 304 vs 520 us at 32 rows of the 151936-row head)
+            logits = ops.gemm_nt(x if idx is None else x.index_select(0, idx[:rows]), self.lm_head)
         else:
             logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
         if self.B == 1:

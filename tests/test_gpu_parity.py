@@ -237,46 +237,28 @@ def test_model_long_prefill_and_decode_vs_oracle():
         close(o1, ro1, what="decode out")
 
 
-def test_split_kv_attention_chunk_strides():
-    """Wide ragged batches give each attention workgroup a stride of 64-key chunks instead of one chunk; forced here
-    on a small model (333-token prompts = 6 chunks over 2 strides): against the oracle, and bit-identical to the
-    one-chunk-per-workgroup grid, over a prefill and several decode steps."""
-    import ctypes
-    from eagle_amd import _hip
-    sw = _hip.lib().eagle_debug_set_attn_splits
-    sw.argtypes, sw.restype = [ctypes.c_int], None
-    dims = dm.DraftDims(hidden=512, inter=256, heads=4, kv_heads=2, vocab=300)  # head_dim 128, grouped kv heads
+def test_split_kv_attention_many_chunks_grouped_kv_heads():
+    """Split-KV attention over several 64-key chunks per head (333-token prompts = 6 chunks) with grouped kv heads
+    (4 query heads on 2 kv heads), against the oracle over a prefill and several decode steps of growing width."""
+    dims = dm.DraftDims(hidden=512, inter=256, heads=4, kv_heads=2, vocab=300)  # head_dim 128
     w = dm.init_weights(dims, seed=11, std=0.05)
     wb = {k: v.to(BF) for k, v in w.items()}
     d = dev()
-    outs = {}
-    try:
-        for forced in (0, 2, 1):
-            sw(forced)
-            m = _model(dims, w)
-            g = torch.Generator().manual_seed(21)
-            h = torch.randn(2, 333, 512, generator=g).to(BF)
-            ids = torch.randint(0, 300, (2, 333), generator=g)
-            got = []
-            with torch.no_grad():
-                ro, rkv = dm.forward(wb, dims, h, ids, use_cache=True)
-                o, kv = m(h.to(d), ids.to(d), use_cache=True)
-                close(o, ro, what="prefill out")
-                got.append(o.cpu())
-                for step in range(3):
-                    q = 1 + 3 * step
-                    h1 = torch.randn(2, q, 512, generator=g).to(BF)
-                    i1 = torch.randint(0, 300, (2, q), generator=g)
-                    ro1, rkv = dm.forward(wb, dims, h1, i1, past_key_values=rkv, use_cache=True)
-                    o1, kv = m(h1.to(d), i1.to(d), past_key_values=kv, use_cache=True)
-                    close(o1, ro1, what="decode step %d" % step)
-                    got.append(o1.cpu())
-            outs[forced] = got
-    finally:
-        sw(0)
-    for forced in (2, 1):
-        for a, b in zip(outs[0], outs[forced]):
-            assert torch.equal(a, b), "chunk-stride grid differs from the one-chunk-per-workgroup grid"
+    m = _model(dims, w)
+    g = torch.Generator().manual_seed(21)
+    h = torch.randn(2, 333, 512, generator=g).to(BF)
+    ids = torch.randint(0, 300, (2, 333), generator=g)
+    with torch.no_grad():
+        ro, rkv = dm.forward(wb, dims, h, ids, use_cache=True)
+        o, kv = m(h.to(d), ids.to(d), use_cache=True)
+        close(o, ro, what="prefill out")
+        for step in range(3):
+            q = 1 + 3 * step
+            h1 = torch.randn(2, q, 512, generator=g).to(BF)
+            i1 = torch.randint(0, 300, (2, q), generator=g)
+            ro1, rkv = dm.forward(wb, dims, h1, i1, past_key_values=rkv, use_cache=True)
+            o1, kv = m(h1.to(d), i1.to(d), past_key_values=kv, use_cache=True)
+            close(o1, ro1, what="decode step %d" % step)
 
 
 # ------------------------------------------------------------------ tree kernels (bit-exact)
