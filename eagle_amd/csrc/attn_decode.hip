@@ -43,12 +43,17 @@ struct AttnDecArgs {
 // workspace record per (b, h, split): [AD_MAXM][AD_MAXHD] fp32 O~  then [AD_MAXM][2] fp32 (m, l)
 #define AD_REC (AD_MAXM * AD_MAXHD + AD_MAXM * 2)
 
+// MM = row capacity of this instantiation (4, 8 or 16 >= M): everything but q_s (all 16 MFMA columns, rows >= M zero) has
+// MM rows, so a 4-row tree step takes 15 KB of LDS and 8 workgroups share a CU where the 16-row layout (48 KB) fits 3
+// -- a wide ragged batch runs tens of workgroups per CU, each a chain of memory latencies (PMC: waves wait 50 % of
+// their cycles at 2 resident waves per SIMD).
+template <int MM>
 __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t q_s[AD_MAXM * AD_MAXHD];
-  __shared__ __attribute__((aligned(16))) bf16_t knew[AD_MAXM * AD_MAXHD];
-  __shared__ __attribute__((aligned(16))) bf16_t vnew[AD_MAXM * AD_MAXHD];
-  __shared__ __attribute__((aligned(16))) float P[AD_MAXM * AD_CH];
-  __shared__ __attribute__((aligned(16))) float red[4][AD_MAXM][AD_MAXHD];
+  __shared__ __attribute__((aligned(16))) bf16_t knew[MM * AD_MAXHD];
+  __shared__ __attribute__((aligned(16))) bf16_t vnew[MM * AD_MAXHD];
+  __shared__ __attribute__((aligned(16))) float P[MM * AD_CH];
+  __shared__ __attribute__((aligned(16))) float red[4][MM][AD_MAXHD];
   __shared__ float rowm[AD_MAXM], rowl[AD_MAXM];
 
   const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -218,14 +223,15 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
       if (tm && vis && cc >= tree0) vis = tm[m * p.T + (cc - tree0)] != 0;
       sc[r] = vis ? rbf(rbf(acc[r]) / p.sqrt_hd) : -INFINITY;
     }
-    *reinterpret_cast<float4*>(&P[m * AD_CH + wave * 16 + 4 * g]) = make_float4(sc[0], sc[1], sc[2], sc[3]);
+    if (m < MM) *reinterpret_cast<float4*>(&P[m * AD_CH + wave * 16 + 4 * g]) = make_float4(sc[0], sc[1], sc[2], sc[3]);
   }
   __syncthreads();
 
   // ---- phase 2: chunk-local softmax numerators: 16 threads per row, 4 keys each ----
   {
     const int m = t >> 4, j = t & 15;
-    float4 v = *reinterpret_cast<const float4*>(&P[m * AD_CH + 4 * j]);
+    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (m < MM) v = *reinterpret_cast<const float4*>(&P[m * AD_CH + 4 * j]);
     float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
@@ -236,16 +242,16 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
     float sum = e.x + e.y + e.z + e.w;
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 16);
-    *reinterpret_cast<float4*>(&P[m * AD_CH + 4 * j]) = e;
+    if (m < MM) *reinterpret_cast<float4*>(&P[m * AD_CH + 4 * j]) = e;
     if (j == 0) { rowm[m] = mx; rowl[m] = sum; }
   }
   __syncthreads();
 
   // ---- phase 3: O~ = P.V ; thread = (2 adjacent d) x (key group) ; V pairs already in registers ----
   {
-    float a0[AD_MAXM], a1[AD_MAXM];
+    float a0[MM], a1[MM];
 #pragma unroll
-    for (int m = 0; m < AD_MAXM; ++m) a0[m] = a1[m] = 0.f;
+    for (int m = 0; m < MM; ++m) a0[m] = a1[m] = 0.f;
 #pragma unroll
     for (int u = 0; u < 16; ++u) {  // rows appended by this call come from LDS
       const int c = c_begin + kg * kpg + u;
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
     }
     if ((kpg & 3) == 0) {
 #pragma unroll
-      for (int m = 0; m < AD_MAXM; ++m) {
+      for (int m = 0; m < MM; ++m) {
         if (m < M) {
 #pragma unroll
           for (int u4 = 0; u4 < 16; u4 += 4) {
@@ -282,7 +288,7 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
     for (int pass = 0; pass < (ngroups + 3) / 4; ++pass) {
       if ((kg >> 2) == pass) {
 #pragma unroll
-        for (int m = 0; m < AD_MAXM; ++m) {
+        for (int m = 0; m < MM; ++m) {
           if (m < M) {
             float* r = &red[slot][m][2 * dp];
             if (pass == 0) { r[0] = a0[m]; r[1] = a1[m]; } else { r[0] += a0[m]; r[1] += a1[m]; }
@@ -381,7 +387,10 @@ extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const 
   a.vec16 = ((hd & 15) == 0) && ((cache_batch_stride & 7) == 0) &&
             (((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(cos_table) | reinterpret_cast<uintptr_t>(sin_table) |
                reinterpret_cast<uintptr_t>(kcache) | reinterpret_cast<uintptr_t>(vcache)) & 15) == 0);
-  hipLaunchKernelGGL(attn_split_kernel, dim3(a.max_splits, H, B), dim3(AD_THREADS), 0, stream, a);
+  const dim3 grid(a.max_splits, H, B), block(AD_THREADS);
+  if (M <= 4) hipLaunchKernelGGL(attn_split_kernel<4>, grid, block, 0, stream, a);
+  else if (M <= 8) hipLaunchKernelGGL(attn_split_kernel<8>, grid, block, 0, stream, a);
+  else hipLaunchKernelGGL(attn_split_kernel<AD_MAXM>, grid, block, 0, stream, a);
   int rc = eagle_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B, (M + 1) / 2), dim3(2 * AD_MAXHD), 0, stream, a);
