@@ -33,9 +33,6 @@ struct GemmArgs {
   int out_f32;                 // 0: bf16 C, 1: fp32 C
   int accumulate;              // C += result (same dtype as C)
   int tiles_m, tiles_n;
-  int ksplit;                  // > 1: grid = tiles x ksplit, slice s multiplies K tiles [s*kchunk, ...) into partial[s]
-  int kchunk;                  // K tiles per slice
-  float* partial;              // [ksplit][M][N] fp32 (split-K only)
 };
 
 __device__ __forceinline__ void gm_stage(const GemmArgs& p, bf16_t* ldsA, bf16_t* ldsB, int m0, int n0, int kt, int tid) {
@@ -66,13 +63,10 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(GemmArgs p) {
 
   // XCD-aware remap: ids b, b+8, ... share an XCD; give each XCD a contiguous run of tiles,
   // and walk M fastest inside the run so that neighbours reuse the same weight (B) panel.
-  const int ntile = p.tiles_m * p.tiles_n;
-  const int nwg = ntile * p.ksplit;
+  const int nwg = p.tiles_m * p.tiles_n;
   const int orig = blockIdx.x;
   const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-  const int wgid0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  const int kslice = wgid0 / ntile;                 // slices of one tile sit ntile ids apart
-  const int wgid = wgid0 - kslice * ntile;
+  const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   const int tn = wgid / p.tiles_m, tm = wgid - tn * p.tiles_m;
   const int m0 = tm * GM_BM, n0 = tn * GM_BN;
 
@@ -82,12 +76,11 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int kt0 = kslice * p.kchunk;
-  const int nk = min(kt0 + p.kchunk, p.K / GM_BK);  // this slice: K tiles [kt0, nk), non-empty (launcher)
-  gm_stage(p, lds[0][0], lds[0][1], m0, n0, kt0, tid);
+  const int nk = p.K / GM_BK;
+  gm_stage(p, lds[0][0], lds[0][1], m0, n0, 0, tid);
   __syncthreads();  // hipcc drains the LDS-DMA (vmcnt(0)) in front of the barrier
   int cur = 0;
-  for (int kt = kt0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) gm_stage(p, lds[cur ^ 1][0], lds[cur ^ 1][1], m0, n0, kt + 1, tid);
     const bf16_t* la = lds[cur][0];
     const bf16_t* lb = lds[cur][1];
@@ -113,22 +106,6 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(GemmArgs p) {
   }
 
   // epilogue: acc[i][j][r] = C[m0 + wm*64 + i*16 + r16][n0 + wn*64 + j*16 + 4g + r]
-  if (p.ksplit > 1) {                               // split-K: raw fp32 partial sums; gemm8_reduce_kernel finishes
-    float* part = p.partial + (int64_t)kslice * p.M * p.N;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + r16;
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int nb = n0 + wn * 64 + j * 16 + 4 * g;
-        float* o = part + (int64_t)m * p.N + nb;
-        if (nb + 3 < p.N && (p.N & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        else for (int rr = 0; rr < 4; ++rr) if (nb + rr < p.N) o[rr] = acc[i][j][rr];
-      }
-    }
-    return;
-  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + i * 16 + r16;
@@ -178,8 +155,6 @@ static inline bool gm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                           const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
                           void* workspace, hipStream_t stream);
-int eagle_launch_splitk_reduce(const float* partial, int ksplit, void* C, int64_t ldc, const void* bias, const void* res,
-                               int64_t ldr, int M, int N, int out_f32, int accumulate, hipStream_t stream);
 static int g_gemm8_mode = -1;   // 0: never, 1: whenever legal, 2: by shape (default); EAGLE_GEMM8 overrides
 extern "C" void eagle_debug_set_gemm8(int mode) { g_gemm8_mode = mode; }
 static bool use_gemm8(int M, int N, int K) {
@@ -209,7 +184,6 @@ extern "C" int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
   a.tiles_m = (M + GM_BM - 1) / GM_BM; a.tiles_n = (N + GM_BN - 1) / GM_BN;
-  a.ksplit = 1; a.kchunk = K / GM_BK; a.partial = nullptr;
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(a.tiles_m * a.tiles_n), dim3(GM_THREADS), 0, stream, a);
   return eagle_check_launch();
 }
@@ -229,29 +203,6 @@ extern "C" int eagle_gemm_nt_splitk_bf16(const void* A, int64_t lda, const void*
   if (M < 1 || N < 1 || K < 2 * GM_BK || (K % GM_BK)) return EAGLE_ERR_SHAPE;
   if ((lda & 7) || (ldb & 7) || lda < K || ldb < K || ldc < N || (res && ldr < N)) return EAGLE_ERR_SHAPE;
   if (!gm_al16(A) || !gm_al16(B) || !gm_al16(C) || !gm_al16(workspace)) return EAGLE_ERR_SHAPE;
-  if (g_gemm8_mode < 0) use_gemm8(M, N, K);         // reads EAGLE_GEMM8 once
-  if (g_gemm8_mode != 1 && M <= 192 && N <= 4096) {
-    // decode batches against the narrow projections (fc, o, down: N = 4096): K slices of the 128x128 kernel, two
-    // workgroups per CU, instead of 256x256 tiles that are half padding (in-cycle at 128-192 rows: o 23 -> 18 us,
-    // down 44 -> 39 us; the wide projections qkv and gate|up stay on the 256x256 slices: 34 vs 43 us, 65 vs 83 us)
-    GemmArgs a;
-    const int nk = K / GM_BK;
-    if (ksplit > nk) ksplit = nk;
-    a.kchunk = (nk + ksplit - 1) / ksplit;
-    a.ksplit = (nk + a.kchunk - 1) / a.kchunk;      // every slice non-empty
-    a.partial = (float*)workspace;
-    a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
-    a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
-    a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
-    a.tiles_m = (M + GM_BM - 1) / GM_BM; a.tiles_n = (N + GM_BN - 1) / GM_BN;
-    if (a.ksplit > 1) {
-      hipLaunchKernelGGL(gemm_nt_kernel, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(GM_THREADS), 0, stream, a);
-      int rc = eagle_check_launch();
-      if (rc) return rc;
-      return eagle_launch_splitk_reduce(a.partial, a.ksplit, C, ldc, bias, res, ldr, M, N, out_f32, accumulate, stream);
-    }
-    return eagle_gemm_nt_bf16(A, lda, B, ldb, C, ldc, bias, res, ldr, M, N, K, out_f32, accumulate, stream);
-  }
   return eagle_launch_gemm_nt8(A, lda, B, ldb, C, ldc, bias, res, ldr, M, N, K, out_f32, accumulate, ksplit, workspace, stream);
 }
 

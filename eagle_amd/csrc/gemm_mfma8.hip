@@ -413,18 +413,6 @@ __global__ __launch_bounds__(256) void gemm8_reduce_kernel(Gemm8Args p) {
   }
 }
 
-// Sum-and-epilogue pass over split-K partials written by either GEMM kernel (gemm_mfma.hip's 128x128 slices too).
-int eagle_launch_splitk_reduce(const float* partial, int ksplit, void* C, int64_t ldc, const void* bias, const void* res,
-                               int64_t ldr, int M, int N, int out_f32, int accumulate, hipStream_t stream) {
-  Gemm8Args a = {};
-  a.partial = const_cast<float*>(partial); a.ksplit = ksplit; a.C = C; a.ldc = ldc;
-  a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
-  a.M = M; a.N = N; a.out_f32 = out_f32; a.accumulate = accumulate;
-  const int64_t q4 = (int64_t)M * ((N + 3) / 4);
-  hipLaunchKernelGGL(gemm8_reduce_kernel, dim3((unsigned)((q4 + 255) / 256)), dim3(256), 0, stream, a);
-  return eagle_check_launch();
-}
-
 static int g_g8_gm = -1;           // EAGLE_GEMM8_GM: row tiles per group (0 = all rows, the plain column-major order)
 extern "C" void eagle_debug_set_gemm8_gm(int gm) { g_g8_gm = gm; }
 static int g_g8_pingpong = -1;     // EAGLE_GEMM8_PINGPONG=0 selects the in-phase schedule (A/B measurements)
