@@ -445,6 +445,13 @@ def main():
 
     from eagle_amd.speculative import EagleDrafter
 
+    t_start = time.perf_counter()
+
+    def note(msg):                                    # progress on stderr (stdout carries the one JSON line)
+        if rank == 0:
+            print(f"[bench {time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    note(f"world {world}, backend {backend if world > 1 else 'none'}: building the draft head")
     cfg, model, lm_head = make_model(a.config, dev, seed=0)
     drafter = EagleDrafter(model, lm_head, expand=a.expand, batch=1, max_ctx=2048)
     n_fw = 1 + len(drafter.tb.steps)
@@ -501,19 +508,24 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, a.expand)
     del drafter, ver, tgt_kv, model, lm_head
     torch.cuda.empty_cache()
+    note("draft/verify leg done")
     if rank == 0 and world == 1 and not a.no_batched:
         out["batched"] = batched_leg(dev)
+        note("batch-32 leg done")
         torch.cuda.empty_cache()
         out["dynamic_tree"] = dynamic_leg(dev)
+        note("dynamic-tree leg done")
         torch.cuda.empty_cache()
     if not a.no_train:
         from eagle_amd.train_bench import train_tokens_per_s
+        note("training leg")
         tr = train_tokens_per_s(dev, rank, world, dist, steps=a.train_steps, warmup=a.train_warmup, ga=a.train_ga,
                                 micro_batch=a.train_micro_batch)
         if rank == 0 and tr is not None:
             if world == 1 and not a.no_cpu_baseline:
                 tr["cpu_baseline"] = cpu_train_baseline()
             out["train"] = tr
+        note("training leg done")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

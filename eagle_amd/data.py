@@ -1,0 +1,68 @@
+"""Host side of the training input path on either side of the hot loop.
+
+``Collator``            eagle/train.py:242-253 without the tokenizer: the reference tokenises chat messages with the
+                        verifier's chat template (needs tokenizer files; out of scope) and pads the batch with id 0
+                        (`pad_token_id = 0`, `padding=True`); here the features are already tokenised
+                        ({"input_ids", "loss_mask"} per conversation, e.g. from `apply_chat_template(...,
+                        return_assistant_tokens_mask=True)` run offline) and only the padding semantics remain.
+``make_eagle_batch``    eagle/train.py:256-269 (`_make_eagle_input`) given the verifier's last hidden state: truncation
+                        to max_model_len, uniform noise (train.py:272-275) drawn on the device, and the shift kernel
+                        (eagle_make_eagle_input_bf16).  Returns the reference's dict keys; the result feeds
+                        EagleTrainer.step / Llama2Model.forward unchanged.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+
+class Collator:
+    """Pads already-tokenised conversations to the longest of the batch: ids with ``pad_token_id`` (0 as in the
+    reference), the assistant mask with 0.  ``padding_side`` follows the tokenizer in the reference ("right" for the
+    Qwen and the fast Llama tokenizers it is used with)."""
+
+    def __init__(self, pad_token_id: int = 0, padding_side: str = "right") -> None:
+        if padding_side not in ("right", "left"):
+            raise ValueError("padding_side must be 'right' or 'left'")
+        self.pad_token_id, self.padding_side = pad_token_id, padding_side
+
+    def __call__(self, features: Sequence[Dict[str, Sequence[int]]]) -> Dict[str, torch.Tensor]:
+        if not features:
+            raise ValueError("empty batch")
+        L = max(len(f["input_ids"]) for f in features)
+        ids = torch.full((len(features), L), self.pad_token_id, dtype=torch.long)
+        mask = torch.zeros((len(features), L), dtype=torch.long)
+        for i, f in enumerate(features):
+            n = len(f["input_ids"])
+            if len(f["loss_mask"]) != n:
+                raise ValueError(f"feature {i}: input_ids and loss_mask differ in length")
+            sl = slice(0, n) if self.padding_side == "right" else slice(L - n, L)
+            ids[i, sl] = torch.as_tensor(f["input_ids"], dtype=torch.long)
+            mask[i, sl] = torch.as_tensor(f["loss_mask"], dtype=torch.long)
+        return {"input_ids": ids, "loss_mask": mask}
+
+
+def make_eagle_batch(batch: Dict[str, torch.Tensor], verifier_hidden: torch.Tensor, max_model_len: int,
+                     transform_uniform_low: float = 0.0, transform_uniform_high: float = 0.0,
+                     generator: Optional[torch.Generator] = None, noise: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """batch = Collator output; verifier_hidden [B, L, D] bf16 on the GPU = the verifier's last hidden state over
+    batch["input_ids"][:, :max_model_len] (the verifier forward is the caller's).  hidden_states = verifier_hidden +
+    U[low, high) noise; target[:, :-1] = hidden_states[:, 1:], last row zero (so the target is noisy too);
+    input_ids shifted left with a trailing 0; loss_mask truncated, not shifted.  ``noise`` (already drawn) overrides
+    the device draw, for reproducible tests."""
+    dev = verifier_hidden.device
+    ids = batch["input_ids"][:, :max_model_len].to(dev)
+    lm = batch["loss_mask"][:, :max_model_len].to(dev)
+    h = verifier_hidden[:, :max_model_len]
+    if h.shape[:2] != ids.shape:
+        raise ValueError(f"verifier_hidden {tuple(h.shape[:2])} does not match input_ids {tuple(ids.shape)}")
+    if noise is None and transform_uniform_high != transform_uniform_low:
+        noise = torch.rand(h.shape, generator=generator, device=dev, dtype=torch.float32)
+        noise = (noise * (transform_uniform_high - transform_uniform_low) + transform_uniform_low).to(h.dtype)
+    elif noise is not None:
+        noise = noise[:, :max_model_len].to(device=dev, dtype=h.dtype)
+    ho, tg, io = ops.make_eagle_input(h, ids, noise)
+    return {"input_ids": io, "hidden_states": ho, "target": tg, "loss_mask": lm}

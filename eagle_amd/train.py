@@ -507,7 +507,18 @@ class EagleTrainer:
             while buckets and buckets[0][0] == name:
                 _, lo, hi = buckets.pop(0)
                 if self.group is not None:
-                    works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                    # RCCL takes a whole bucket in one asynchronous call that overlaps the rest of the backward.  gloo (CPU
+                    # tests, and the rehearsal of N ranks on fewer GPUs) never returns from an all-reduce of a device tensor
+                    # issued while this rank's kernels are still queued (measured on this image: with the device idle the
+                    # same call takes 20 ms), so there the device is drained first and the pieces are blocking: the
+                    # same collective sequence, no overlap -- a rehearsal of the logic, not of the timing.
+                    if dist.get_backend(self.group) != "gloo":
+                        works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                    else:
+                        if self.grad.is_cuda:
+                            torch.cuda.synchronize()
+                        for a in range(lo, hi, 16 * 1024 * 1024):
+                            dist.all_reduce(self.grad[a:min(a + 16 * 1024 * 1024, hi)], op=dist.ReduceOp.AVG, group=self.group)
         return on_ready
 
     def _optimizer_step(self):

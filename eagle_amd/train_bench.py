@@ -124,6 +124,9 @@ def train_tokens_per_s(dev, rank: int, world: int, dist, steps: int = 6, warmup:
 
     for s in range(warmup):
         tr.step(pool[s % 2])
+        if rank == 0:
+            import sys
+            print(f"[train_bench] warm-up step {s} issued", file=sys.stderr, flush=True)
     sync()
     t0 = time.perf_counter()
     for s in range(steps):
