@@ -44,10 +44,14 @@ struct AttnDecArgs {
 #define AD_REC (AD_MAXM * AD_MAXHD + AD_MAXM * 2)
 
 // MM = row capacity of this instantiation (4, 8 or 16 >= M): everything but q_s (all 16 MFMA columns, rows >= M zero) has
-// MM rows, so a 4-row tree step takes 15 KB of LDS and 8 workgroups share a CU where the 16-row layout (48 KB) fits 3
+// MM rows, so a 4-row tree step takes 15 KB of LDS and 4 workgroups (116 registers per lane) share a CU where the 16-row
+// layout (48 KB) fits 3
 // -- a wide ragged batch runs tens of workgroups per CU, each a chain of memory latencies (PMC: waves wait 50 % of
 // their cycles at 2 resident waves per SIMD).
-template <int MM>
+// HD = compile-time head_dim (128, both shipped configs) or 0 = read it from the arguments: with the constant every
+// index division, the key-group geometry and the small-head_dim paths fold away (the kernel is VALU- and
+// latency-bound on wide batches: PMC 61 % VALU-busy, a third of it integer and predicate work).
+template <int MM, int HD>
 __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t q_s[AD_MAXM * AD_MAXHD];
   __shared__ __attribute__((aligned(16))) bf16_t knew[MM * AD_MAXHD];
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(AD_THREADS) void attn_split_kernel(AttnDecArgs p) {
   __shared__ float rowm[AD_MAXM], rowl[AD_MAXM];
 
   const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int hd = p.hd, M = p.M;
+  const int hd = HD ? HD : p.hd, M = p.M;
   const int rep = p.H / p.HK, hk = h / rep;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int past = p.past_len[b] + p.past_off;
@@ -388,9 +392,10 @@ extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const 
             (((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(cos_table) | reinterpret_cast<uintptr_t>(sin_table) |
                reinterpret_cast<uintptr_t>(kcache) | reinterpret_cast<uintptr_t>(vcache)) & 15) == 0);
   const dim3 grid(a.max_splits, H, B), block(AD_THREADS);
-  if (M <= 4) hipLaunchKernelGGL(attn_split_kernel<4>, grid, block, 0, stream, a);
-  else if (M <= 8) hipLaunchKernelGGL(attn_split_kernel<8>, grid, block, 0, stream, a);
-  else hipLaunchKernelGGL(attn_split_kernel<AD_MAXM>, grid, block, 0, stream, a);
+  if (hd != 128) hipLaunchKernelGGL((attn_split_kernel<AD_MAXM, 0>), grid, block, 0, stream, a);
+  else if (M <= 4) hipLaunchKernelGGL((attn_split_kernel<4, 128>), grid, block, 0, stream, a);
+  else if (M <= 8) hipLaunchKernelGGL((attn_split_kernel<8, 128>), grid, block, 0, stream, a);
+  else hipLaunchKernelGGL((attn_split_kernel<AD_MAXM, 128>), grid, block, 0, stream, a);
   int rc = eagle_check_launch();
   if (rc) return rc;
   hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B, (M + 1) / 2), dim3(2 * AD_MAXHD), 0, stream, a);
