@@ -150,86 +150,35 @@ def draft_bwd(W: LayerWeights, saved, dout: torch.Tensor, B: int, L: int, H: int
     x0, x, qkv, attn, lse, h1, n, rstd, gu, act = saved
     acc = sink.accumulate
     ready = on_ready or (lambda name: None)
-    # The wgrad operands ([rows, C] -> [C, rows padded to the GEMM's K step]) are transposed on a SIDE stream, each
-    # issued before the dgrad GEMM that runs beside it: the transposes are HBM-bound and small (8 KB of LDS, one wave
-    # per SIMD), the GEMMs MFMA-bound with 32 KB of LDS to spare per CU, so the two share the CUs and the 24
-    # transposes of a step (3.6 % of it when serialised) mostly disappear under the GEMMs.
-    on_gpu = dout.is_cuda                      # (the host-logic tests run this driver over CPU stand-ins of the kernels)
-    main = torch.cuda.current_stream() if on_gpu else None
-    side = _side_stream(dout.device) if (_SIDE_TRANSPOSES and on_gpu) else None
-
-    def T(t):
-        """Transpose on the side stream (after everything queued on the main stream so far); returns a handle whose
-        ``get()`` makes the main stream wait for it."""
-        if side is None:
-            return _Ready(ops.transpose(t, pad_to=64), None, None)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            out = ops.transpose(t, pad_to=64)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        return _Ready(out, ev, main)
-
-    # activations of the forward: all five are ready now
-    actT, nT, attnT, xT, x0T = T(act), T(n), T(attn), T(x), T(x0)
-    doutT = T(dout)
+    def T(t):                                                     # [rows, C] -> [C, rows padded to the GEMM's K step]
+        return ops.transpose(t, pad_to=64)
     # down_proj: out = act . Wdown^T + h1
     d_act = ops.gemm_nt(dout, tc.get("wdown", W.wdown))
-    ops.gemm_nt(doutT.get(), actT.get(), out=sink.wdown, accumulate=acc)
+    doutT = T(dout)
+    ops.gemm_nt(doutT, T(act), out=sink.wdown, accumulate=acc)
     ready("wdown")
     dgu = ops.silu_mul_bwd(gu, d_act)
     del d_act
-    dguT = T(dgu)
     dn = ops.gemm_nt(dgu, tc.get("wgu", W.wgu))
-    ops.gemm_nt(dguT.get(), nT.get(), out=sink.wgu, accumulate=acc)
+    ops.gemm_nt(T(dgu), T(n), out=sink.wgu, accumulate=acc)
     ready("wgu")
-    del dgu, dguT
+    del dgu
     dh1, _ = ops.rmsnorm_bwd(dn, h1, W.wn, rstd, res=dout, dw=sink.wn, accumulate_dw=acc)   # + residual branch
     ready("wn")
-    dh1T = T(dh1)
     d_attn = ops.gemm_nt(dh1, tc.get("wo", W.wo))
-    ops.gemm_nt(dh1T.get(), attnT.get(), out=sink.wo, accumulate=acc)
+    dh1T = T(dh1)
+    ops.gemm_nt(dh1T, T(attn), out=sink.wo, accumulate=acc)
     ready("wo")
     dqkv = ops.attn_train_bwd(qkv, attn, d_attn, lse, B, L, H, hd)
     ops.rope_qk_(dqkv, cos, sin, L, 2 * H, hd, position_ids=position_ids, inverse=True)
-    dqkvT = T(dqkv)
     dx = ops.gemm_nt(dqkv, tc.get("wqkv", W.wqkv), res=dh1)       # + residual branch of :385
-    ops.gemm_nt(dqkvT.get(), xT.get(), out=sink.wqkv, accumulate=acc)
+    ops.gemm_nt(T(dqkv), T(x), out=sink.wqkv, accumulate=acc)
     ready("wqkv")
     dxT = T(dx)
+    ops.gemm_nt(dxT, T(x0), out=sink.fc_w, accumulate=acc)
     if sink.fc_b is not None:
         ops.colsum(dx, sink.fc_b, accumulate=acc)
-    ops.gemm_nt(dxT.get(), x0T.get(), out=sink.fc_w, accumulate=acc)
     ready("fc")
-    if side is not None:
-        side.wait_stream(main)     # the side stream's buffers are released only after their last reader on the main stream
-
-
-import os as _os
-
-_SIDE_TRANSPOSES = _os.environ.get("EAGLE_TRAIN_SIDE_STREAM", "1") != "0"
-_SIDE_STREAMS: dict = {}
-
-
-def _side_stream(device) -> "torch.cuda.Stream":
-    key = (device.type, device.index)
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    return _SIDE_STREAMS[key]
-
-
-class _Ready:
-    """A tensor produced on another stream plus the event that says it is complete."""
-
-    def __init__(self, tensor, event, consumer):
-        self.tensor, self.event, self.consumer = tensor, event, consumer
-
-    def get(self) -> torch.Tensor:
-        if self.event is not None:
-            self.consumer.wait_event(self.event)
-            self.tensor.record_stream(self.consumer)   # allocated on the side stream, read on the main stream
-            self.event = None
-        return self.tensor
 
 
 def loss_fwd_bwd(predict: torch.Tensor, target: torch.Tensor, lm_head: torch.Tensor, lm_head_t: Optional[torch.Tensor],
