@@ -51,9 +51,21 @@ __device__ __forceinline__ unsigned long long wave_umax64(unsigned long long v) 
 }
 
 // ---- stage 1, bf16: 32-bit keys ----
+// (m, s) <- log-sum-exp merge with (m2, s2): running maximum and sum of exp(x - m)
+__device__ __forceinline__ void tk_lse_merge(float& m, float& s, float m2, float s2) {
+  const float M = fmaxf(m, m2);
+  if (M == -INFINITY) return;
+  s = s * __expf(m - M) + s2 * __expf(m2 - M);
+  m = M;
+}
+
+// lse_part (may be null): [rows][nwc] (max, sum of exp(x - max)) of every wave chunk, for a row log-sum-exp out of the
+// same pass over the logits (the dynamic tree scores candidates by softmax probability: eagle_topk_lse_vocab).
+template <bool LSE>
 __global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, int k,
                                                                      int nwc, unsigned long long* __restrict__ cand,
-                                                                     const int64_t* __restrict__ block_index, int64_t block_rows) {
+                                                                     const int64_t* __restrict__ block_index, int64_t block_rows,
+                                                                     float2* __restrict__ lse_part) {
   const int row = blockIdx.y;
   if (block_index) x += *block_index * block_rows * ld;
   const int lane = threadIdx.x & 63;
@@ -79,6 +91,30 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16
       // invalid slots get key 0
       key[i] = idx < V ? ((mono_bf16(xr[idx]) << 16) | (uint32_t)(TK_WCHUNK - 1 - (lane * TK_PER_LANE + i))) : 0u;
     }
+  }
+  if (LSE) {
+    // the monotone key orders the values, so the lane's maximum comes from its best key; elements that are -inf,
+    // NaN or beyond V contribute nothing (as in row_lse_kernel)
+    float f[TK_PER_LANE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < TK_PER_LANE; ++i) {
+      const int idx = base + i;
+      const float v = idx < V ? bf2f(xr[idx]) : -INFINITY;
+      f[i] = (v > -INFINITY) ? v : -INFINITY;          // NaN compares false
+      mx = fmaxf(mx, f[i]);
+    }
+    float sm = 0.f;
+    if (mx > -INFINITY) {
+#pragma unroll
+      for (int i = 0; i < TK_PER_LANE; ++i) sm += __expf(f[i] - mx);   // exp(-inf) = 0
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float m2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(sm, o, 64);
+      tk_lse_merge(mx, sm, m2, s2);
+    }
+    if (lane == 0) lse_part[(int64_t)row * nwc + wc] = make_float2(mx, sm);
   }
   // valid keys are > 0: the smallest value part is 0x007f (-inf); NaN patterns map to 0xffff
   uint32_t best = 0;
@@ -142,11 +178,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_f32_kernel(const float
   }
 }
 
-template <typename T>
+template <typename T, bool LSE>
 __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
                                                                 const T* __restrict__ x, int64_t ld,
                                                                 int64_t* __restrict__ out_idx, T* __restrict__ out_val,
-                                                                const int64_t* __restrict__ block_index, int64_t block_rows) {
+                                                                const int64_t* __restrict__ block_index, int64_t block_rows,
+                                                                const float2* __restrict__ lse_part, int nwc,
+                                                                float* __restrict__ lse_out) {
   __shared__ unsigned long long surv[4 * TK_MAXK];
   if (block_index) x += *block_index * block_rows * ld;
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -172,6 +210,19 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
     }
   }
   __syncthreads();
+  if (LSE && wave == 1) {                  // row log-sum-exp from the stage-1 partials, beside wave 0's final merge
+    float m = -INFINITY, sm = 0.f;
+    for (int c = lane; c < nwc; c += 64) {
+      const float2 q = lse_part[(int64_t)row * nwc + c];
+      tk_lse_merge(m, sm, q.x, q.y);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(sm, o, 64);
+      tk_lse_merge(m, sm, m2, s2);
+    }
+    if (lane == 0) lse_out[row] = m + __logf(sm);
+  }
   if (wave != 0) return;
   unsigned long long mine = 0;
   if (lane < 4 * k) mine = surv[(lane / k) * TK_MAXK + (lane % k)];
@@ -191,30 +242,50 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
 
 extern "C" int64_t eagle_topk_workspace_bytes(int rows, int V, int k) {
   const int64_t nwc = (V + TK_WCHUNK - 1) / TK_WCHUNK;
-  return (int64_t)rows * nwc * k * 8;
+  return (int64_t)rows * nwc * (k + 1) * 8;     // k candidates + one (max, sum-exp) partial per wave chunk
 }
 
-// dtype: 0 = bf16 logits, 1 = fp32 logits
-extern "C" int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V, int k,
-                                int64_t* out_idx, void* out_val, void* workspace, const int64_t* block_index,
-                                int64_t block_rows, hipStream_t stream) {
+static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int V, int k, int64_t* out_idx, void* out_val,
+                       void* workspace, const int64_t* block_index, int64_t block_rows, float* lse_out, hipStream_t stream) {
   if (!logits || !out_idx || !workspace) return EAGLE_ERR_ARG;
   if (block_index && block_rows < rows) return EAGLE_ERR_SHAPE;
   if (rows < 1 || V < 1 || k < 1 || k > TK_MAXK || ld < V) return EAGLE_ERR_SHAPE;
   const int nwc = (V + TK_WCHUNK - 1) / TK_WCHUNK;
   if ((int64_t)nwc * k > TK_THREADS * TK_CM) return EAGLE_ERR_SHAPE;
   unsigned long long* cand = (unsigned long long*)workspace;
+  float2* part = lse_out ? reinterpret_cast<float2*>(cand + (int64_t)rows * nwc * k) : nullptr;
   dim3 g1((nwc + 3) / 4, rows);
-  if (dtype == 0) {
-    hipLaunchKernelGGL(topk_stage1_bf16_kernel, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand, block_index, block_rows);
-    hipLaunchKernelGGL(topk_stage2_kernel<bf16_t>, dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
-                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows);
-  } else if (dtype == 1) {
+  if (dtype == 0 && lse_out) {
+    hipLaunchKernelGGL(topk_stage1_bf16_kernel<true>, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand,
+                       block_index, block_rows, part);
+    hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, true>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out);
+  } else if (dtype == 0) {
+    hipLaunchKernelGGL(topk_stage1_bf16_kernel<false>, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand,
+                       block_index, block_rows, part);
+    hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out);
+  } else if (dtype == 1 && !lse_out) {
     hipLaunchKernelGGL(topk_stage1_f32_kernel, g1, dim3(TK_THREADS), 0, stream, (const float*)logits, ld, V, k, nwc, cand, block_index, block_rows);
-    hipLaunchKernelGGL(topk_stage2_kernel<float>, dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
-                       (const float*)logits, ld, out_idx, (float*)out_val, block_index, block_rows);
+    hipLaunchKernelGGL((topk_stage2_kernel<float, false>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+                       (const float*)logits, ld, out_idx, (float*)out_val, block_index, block_rows, (const float2*)nullptr, nwc,
+                       (float*)nullptr);
   } else {
     return EAGLE_ERR_ARG;
   }
   return eagle_check_launch();
+}
+
+// dtype: 0 = bf16 logits, 1 = fp32 logits
+extern "C" int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V, int k,
+                                int64_t* out_idx, void* out_val, void* workspace, const int64_t* block_index,
+                                int64_t block_rows, hipStream_t stream) {
+  return topk_launch(logits, ld, dtype, rows, V, k, out_idx, out_val, workspace, block_index, block_rows, nullptr, stream);
+}
+
+// bf16 logits: the top-k of eagle_topk_vocab plus lse_out[rows] = fp32 log-sum-exp of every row, from the same pass
+extern "C" int eagle_topk_lse_vocab(const void* logits, int64_t ld, int rows, int V, int k, int64_t* out_idx, void* out_val,
+                                    float* lse_out, void* workspace, hipStream_t stream) {
+  if (!lse_out) return EAGLE_ERR_ARG;
+  return topk_launch(logits, ld, 0, rows, V, k, out_idx, out_val, workspace, nullptr, 0, lse_out, stream);
 }

@@ -12,7 +12,7 @@ Everything between "the verifier produced logits for the tree" and "the next tre
 HIP kernels with device-resident state and static shapes (batch 1), like ``EagleDrafter``:
   draft forward    eagle_gemm_skinny_bf16 / eagle_tree_attention_bf16 (the tree mask of a step is the
                    device buffer the previous selection wrote)
-  top-k + lse      eagle_topk_vocab, eagle_row_lse_bf16
+  top-k + lse      eagle_topk_lse_vocab (one pass over the logits)
   selection        eagle_dyn_step, eagle_dyn_finalize
   verification     eagle_topk_vocab (k = 1), eagle_dyn_accept, eagle_kv_compact_bf16,
                    eagle_gather_accepted_bf16
@@ -86,8 +86,8 @@ class EagleDynamicDrafter:
     # ------------------------------------------------------------------ draft side
     def _head(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int):
         logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
-        ops.topk(logits, self.k, out_idx=self.ids[:rows], out_val=self.vals[:rows], workspace=self._ws)
-        ops.row_lse(logits, out=self.lse[:rows])
+        # top-k and the rows' log-sum-exp out of one pass over the logits (two launches, not three)
+        ops.topk(logits, self.k, out_idx=self.ids[:rows], out_val=self.vals[:rows], workspace=self._ws, lse_out=self.lse[:rows])
         if self.keep_debug:
             self.debug.append({"logits": logits.clone(), "vals": self.vals[:rows].clone(), "ids": self.ids[:rows].clone(),
                                "lse": self.lse[:rows].clone()})

@@ -299,7 +299,7 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
 def topk(logits: torch.Tensor, k: int, want_values: bool = True,
          out_idx: Optional[torch.Tensor] = None, out_val: Optional[torch.Tensor] = None,
          workspace: Optional[torch.Tensor] = None, block_index: Optional[torch.Tensor] = None,
-         rows: Optional[int] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+         rows: Optional[int] = None, lse_out: Optional[torch.Tensor] = None) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
     """(values, indices) of the k largest per row: value desc, index asc.  logits [rows, V].
     block_index (device int64 scalar) + rows: logits is a ring [blocks*rows, V] and block
     ``block_index[0]`` is read (cursor in device memory: graph-capturable)."""
@@ -324,6 +324,15 @@ def topk(logits: torch.Tensor, k: int, want_values: bool = True,
         out_val = torch.empty((rows, k), dtype=logits.dtype, device=logits.device)
     nb = query("eagle_topk_workspace_bytes", rows, V, k)
     ws = workspace if workspace is not None else _workspace(nb, logits.device)
+    if ws.numel() * ws.element_size() < nb:
+        raise ValueError("topk: workspace too small")
+    if lse_out is not None:
+        # bf16 only: fp32 log-sum-exp of every row from the same pass (eagle_topk_lse_vocab)
+        if dt != 0 or block_index is not None or lse_out.dtype != torch.float32 or lse_out.numel() < rows:
+            raise ValueError("topk: lse_out needs bf16 logits, no ring cursor and an fp32 [rows] output")
+        call("eagle_topk_lse_vocab", ptr(logits), logits.stride(0), rows, V, k, ptr(out_idx),
+             ptr(out_val) if want_values else None, ptr(lse_out), ptr(ws), stream())
+        return (out_val if want_values else None), out_idx
     call("eagle_topk_vocab", ptr(logits), logits.stride(0), dt, rows, V, k, ptr(out_idx),
          ptr(out_val) if want_values else None, ptr(ws), ptr(block_index), rows, stream())
     return (out_val if want_values else None), out_idx

@@ -146,6 +146,12 @@ int64_t eagle_topk_workspace_bytes(int rows, int V, int k);
 int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V, int k,
                      int64_t* out_idx, void* out_val, void* workspace, const int64_t* block_index,
                      int64_t block_rows, eagle_stream_t stream);
+/* bf16 logits: the same top-k plus lse_out[rows] = fp32 log-sum-exp of every row out of the same pass over the logits
+ * (stage 1 leaves a (max, sum-exp) pair per 1024-logit chunk, stage 2 merges them beside its final select) -- what
+ * the dynamic tree's cumulative scores need (candidate probability = exp(logit - lse)) without a
+ * separate eagle_row_lse_bf16 launch.  Same workspace query. */
+int eagle_topk_lse_vocab(const void* logits, int64_t ld, int rows, int V, int k, int64_t* out_idx, void* out_val,
+                         float* lse_out, void* workspace, eagle_stream_t stream);
 
 /* Static-tree kernels (Llama2Model.init_tree / tree_mask hooks,
  * eagle/llama2.py:453-458 -- the algorithm itself is the upstream EAGLE-1 one). */

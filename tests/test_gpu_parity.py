@@ -147,6 +147,26 @@ def test_topk_bit_exact(rows, V, dtype):
     assert torch.equal(ops.first_argmax(x.to(dev())).cpu(), ot.first_argmax(x))
 
 
+@pytest.mark.parametrize("rows,V", [(1, 32000), (8, 32000), (3, 151936), (5, 1000), (2, 4097)])
+def test_topk_with_row_lse_from_the_same_pass(rows, V):
+    """eagle_topk_lse_vocab: ids / values bit-exact as eagle_topk_vocab, lse against fp32 torch.logsumexp and the
+    stand-alone row_lse kernel; rows with -inf entries and an all -inf row included."""
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(rows * 3 + V)
+    x = (torch.randn(rows, V, generator=g) * 4).to(BF)
+    x[0, ::7] = float("-inf")
+    if rows > 1:
+        x[-1] = float("-inf"); x[-1, V // 2] = 1.5            # a single finite entry: lse = that entry
+    xd = x.to(dev())
+    lse = torch.empty(rows, dtype=torch.float32, device=dev())
+    v, i = ops.topk(xd, 10, lse_out=lse)
+    ev, ei = ot.stable_topk(x, 10)
+    assert torch.equal(i.cpu(), ei) and torch.equal(v.cpu(), ev)
+    ref = torch.logsumexp(x.float(), dim=1)
+    assert torch.allclose(lse.cpu(), ref, rtol=1e-5, atol=1e-4), (lse.cpu(), ref)
+    assert torch.allclose(lse, ops.row_lse(xd), rtol=1e-5, atol=1e-4)
+
+
 def test_topk_tie_and_special_values():
     from eagle_amd import ops
     x = torch.zeros(4, 5000, dtype=BF)
