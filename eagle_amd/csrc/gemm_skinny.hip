@@ -431,16 +431,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
 // for all of the block's rows (no per-tile-step re-read of x through L2: at 8 tokens that re-read
 // is half as many bytes again as the weight stream), the RMSNorm row statistics are computed once,
 // and the super-step loop is fully unrolled: stage parity, x fragment and refill target are static.
-// MT = activation tiles of 16 rows (1: up to 16 rows, 2: up to 32): the weight fragments of a super-step are multiplied
-// with every tile's x fragments, so 32 rows still cost ONE pass over the weights (the x fragments of both tiles stay in
-// registers: 2 x 64 VGPRs at K = 4096; the block runs alone on its CU, two waves per SIMD).
-template <int RT, int EPI, int NI, bool NT, int MT = 1>
+template <int RT, int EPI, int NI, bool NT>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
   static_assert((NI & 1) == 0, "two register stages alternate");
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;
   constexpr int RPS = RTW * 16;
-  __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][RT * MT][64][4];
-  __shared__ float red_ss[SK_WAVES][16 * MT];
+  __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][RT][64][4];
+  __shared__ float red_ss[SK_WAVES][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int row_lo = blockIdx.x * rows_per_block;
@@ -448,6 +445,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   if (row_lo >= row_hi) return;
   const int n_ts = (row_hi - row_lo + RPS - 1) / RPS;
   const bool do_norm = p.norm_eps > 0.f;
+  const bool mvalid = r16 < p.M;
 
   bf16x8 a[2][4][RT];
   auto load_w = [&](bf16x8 (&st)[4][RT], int ts, int it) {
@@ -466,119 +464,102 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   load_w(a[0], 0, 0);
   load_w(a[1], 0, 1);
   // activation rows (possibly gathered: two dependent index loads) -> registers, once
-  bf16x8 xk[MT][NI][4];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m = r16 + 16 * mt;
+  const bf16_t* xa;
+  const bf16_t* xb;
+  {
     int64_t ra = 0, rb = 0;
-    if (m < p.M) {
+    if (mvalid) {
+      const int m = r16;
       if (p.ind0) ra = p.idx0[(int64_t)(m / p.ind_n) * p.idx0_bstride + p.ind0[m % p.ind_n]];
       else ra = p.idx0 ? p.idx0[m] : m;
       rb = p.idx1 ? p.idx1[m] : m;
     }
-    const bf16_t* xa = p.x0 + ra * p.ld0 + 8 * g;
-    const bf16_t* xb = p.x1 ? (p.x1 + rb * p.ld1 + 8 * g - p.K0) : xa;
+    xa = p.x0 + ra * p.ld0 + 8 * g;
+    xb = p.x1 ? (p.x1 + rb * p.ld1 + 8 * g - p.K0) : xa;
+  }
+  bf16x8 xk[NI][4];
+#pragma unroll
+  for (int it = 0; it < NI; ++it)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k = ((wave + SK_WAVES * it) << 7) + s * 32;
+      xk[it][s] = *reinterpret_cast<const bf16x8*>(((k < p.K0) ? xa : xb) + k);
+    }
+  float rstd = 1.f;
+  if (do_norm) {
+    float ssq = 0.f;
 #pragma unroll
     for (int it = 0; it < NI; ++it)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int k = ((wave + SK_WAVES * it) << 7) + s * 32;
-        xk[mt][it][s] = *reinterpret_cast<const bf16x8*>(((k < p.K0) ? xa : xb) + k);
-      }
-  }
-  float rstd[MT];
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) rstd[mt] = 1.f;
-  if (do_norm) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float ssq = 0.f;
-#pragma unroll
-      for (int it = 0; it < NI; ++it)
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { const float xv = (float)xk[mt][it][s][j]; ssq = fmaf(xv, xv, ssq); }
-      ssq += __shfl_xor(ssq, 16, 64);
-      ssq += __shfl_xor(ssq, 32, 64);
-      if (g == 0) red_ss[wave][16 * mt + r16] = ssq;
-    }
+        for (int j = 0; j < 8; ++j) { const float xv = (float)xk[it][s][j]; ssq = fmaf(xv, xv, ssq); }
+    ssq += __shfl_xor(ssq, 16, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (g == 0) red_ss[wave][r16] = ssq;
     __syncthreads();
+    float v = 0.f;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      float v = 0.f;
-#pragma unroll
-      for (int w = 0; w < SK_WAVES; ++w) v += red_ss[w][16 * mt + r16];
-      rstd[mt] = rsqrtf(v / (float)p.K + p.norm_eps);
-    }
+    for (int w = 0; w < SK_WAVES; ++w) v += red_ss[w][r16];
+    rstd = rsqrtf(v / (float)p.K + p.norm_eps);
   }
 
-  f32x4 acc[RT][MT];
+  f32x4 acc[RT];
   for (int ts = 0; ts < n_ts; ++ts) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[t][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < RT; ++t)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[t][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it & 1][s][t], xk[mt][it][s], acc[t][mt], 0, 0, 0);
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it & 1][s][t], xk[it][s], acc[t], 0, 0, 0);
       // refill this stage with the super-step two ahead (past the last tile-step: clamped rows)
       load_w(a[it & 1], ts + (it + 2) / NI, (it + 2) % NI);
     }
     const int parity = ts & 1;
 #pragma unroll
-    for (int t = 0; t < RT; ++t)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(&red[parity][wave][t * MT + mt][lane][0]) = acc[t][mt];
+    for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(&red[parity][wave][t][lane][0]) = acc[t];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave == (ts & (SK_WAVES - 1))) {
+      f32x4 sum[RT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        f32x4 sum[RT];
+      for (int t = 0; t < RT; ++t) {
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < RT; ++t) {
-          f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int w = 0; w < SK_WAVES; ++w) sv += *reinterpret_cast<const f32x4*>(&red[parity][w][t][lane][0]);
+        sum[t] = sv * rstd;
+      }
+      const int m = r16;
+      if (m < p.M) {
 #pragma unroll
-          for (int w = 0; w < SK_WAVES; ++w) sv += *reinterpret_cast<const f32x4*>(&red[parity][w][t * MT + mt][lane][0]);
-          sum[t] = sv * rstd[mt];
-        }
-        const int m = r16 + 16 * mt;
-        if (m < p.M) {
+        for (int u = 0; u < RTW; ++u) {
+          const int nb = row_lo + ts * RPS + u * 16 + 4 * g;
+          float y[4];
+          if (EPI == EPI_SILU_MUL) {
 #pragma unroll
-          for (int u = 0; u < RTW; ++u) {
-            const int nb = row_lo + ts * RPS + u * 16 + 4 * g;
-            float y[4];
-            if (EPI == EPI_SILU_MUL) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const float gt = rbf(sum[2 * u][r]), up = rbf(sum[2 * u + 1][r]);
-                y[r] = rbf(gt / (1.0f + __expf(-gt))) * up;
-              }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int n = nb + r;
-                float v = sum[u][r];
-                if (p.bias && n < row_hi) v += bf2f(p.bias[n]);
-                v = rbf(v);
-                if (p.res && n < row_hi) v = v + bf2f(p.res[(int64_t)m * p.ldr + n]);
-                y[r] = v;
-              }
+            for (int r = 0; r < 4; ++r) {
+              const float gt = rbf(sum[2 * u][r]), up = rbf(sum[2 * u + 1][r]);
+              y[r] = rbf(gt / (1.0f + __expf(-gt))) * up;
             }
-            bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
-            if (nb + 3 < row_hi && ((p.ldo | nb) & 3) == 0) {
-              uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
-              *reinterpret_cast<uint2*>(o) = v;
-            } else {
-              for (int r = 0; r < 4; ++r) if (nb + r < row_hi) o[r] = f2bf(y[r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int n = nb + r;
+              float v = sum[u][r];
+              if (p.bias && n < row_hi) v += bf2f(p.bias[n]);
+              v = rbf(v);
+              if (p.res && n < row_hi) v = v + bf2f(p.res[(int64_t)m * p.ldr + n]);
+              y[r] = v;
             }
+          }
+          bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
+          if (nb + 3 < row_hi && ((p.ldo | nb) & 3) == 0) {
+            uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+            *reinterpret_cast<uint2*>(o) = v;
+          } else {
+            for (int r = 0; r < 4; ++r) if (nb + r < row_hi) o[r] = f2bf(y[r]);
           }
         }
       }
@@ -586,8 +567,6 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   }
 }
 
-static int g_sk_keepx32 = 1;        // 0: 17..32 rows take the first-generation kernel (A/B measurements)
-extern "C" void eagle_debug_set_skinny_keepx32(int on) { g_sk_keepx32 = on; }
 static int g_skinny_variant = -1;   // -1: read EAGLE_SKINNY_VARIANT once; 0: tile kernel, 1: streaming kernel
 static int g_sk_blocks_per_cu = 2;
 static int g_sk_min_rows = 16;
@@ -635,15 +614,15 @@ static bool sk_stream_nt(const SkinnyArgs& a, int epi) {
   return true;
 }
 
-template <int RT, int EPI, int MT = 1>
+template <int RT, int EPI>
 static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
   int grid = sk_num_cus();                             // ~160 VGPRs: one 8-wave block per CU
   int R = (a.N + grid - 1) / grid;
   if (R < 16) R = 16;
   R = (R + 3) & ~3;
   grid = (a.N + R - 1) / R;
-  if (sk_stream_nt(a, EPI)) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, MT>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
-  else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, MT>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  if (sk_stream_nt(a, EPI)) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
   return eagle_check_launch();
 }
 
@@ -716,10 +695,6 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
       if (epi == EPI_SILU_MUL) rc = launch_skinny_keepx<2, EPI_SILU_MUL>(a, stream);
       else if (N >= 8192) rc = launch_skinny_keepx<2, EPI_LINEAR>(a, stream);
       else rc = launch_skinny_keepx<1, EPI_LINEAR>(a, stream);
-    } else if (mc <= 32 && K == 128 * SK_WAVES * 4 && g_sk_keepx32 && (var == 2 || (var == 3 && big))) {
-      // 17..32 rows against a big K = 4096 matrix: both 16-row tiles ride on one weight pass
-      if (epi == EPI_SILU_MUL) rc = launch_skinny_keepx<2, EPI_SILU_MUL, 2>(a, stream);
-      else rc = launch_skinny_keepx<2, EPI_LINEAR, 2>(a, stream);
     } else if (mc <= 16 && (K & 127) == 0 && K >= 128 * SK_WAVES && (var == 1 || var == 2 || (var == 3 && K >= 8192))) {
       if (epi == EPI_SILU_MUL) rc = launch_skinny_stream<2, EPI_SILU_MUL>(a, stream);
       else if (N >= 8192) rc = launch_skinny_stream<2, EPI_LINEAR>(a, stream);
