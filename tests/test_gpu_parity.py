@@ -328,6 +328,59 @@ def test_greedy_accept_and_compaction_bit_exact():
         assert sorted(set(res[:, 1].tolist())) != [0], "test inputs should accept something"
 
 
+def _random_tree(g, topk, max_depth, max_nodes):
+    """A random prefix-closed set of choice paths (every path's parent is in the set)."""
+    paths = {(int(torch.randint(0, topk, (1,), generator=g)),)}
+    while len(paths) < max_nodes:
+        parent = sorted(paths)[int(torch.randint(0, len(paths), (1,), generator=g))]
+        if torch.rand(1, generator=g) < 0.3:
+            paths.add((int(torch.randint(0, topk, (1,), generator=g)),))
+        elif len(parent) < max_depth:
+            paths.add(parent + (int(torch.randint(0, topk, (1,), generator=g)),))
+    return [list(p_) for p_ in sorted(paths, key=lambda q: (len(q), q))]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_greedy_accept_random_trees_and_tiny_vocabularies(seed):
+    """Acceptance, candidate tables and compaction against the oracle on RANDOM static trees (depth <= 5, 5..40 nodes,
+    top-k 4..10) with a vocabulary of 3..6 tokens, so that sibling nodes repeat tokens, several paths tie in accepted
+    length (first path wins) and whole paths get accepted: bit-exact."""
+    from eagle_amd import ops
+    from eagle_amd.tree import TreeBuffers
+    d = dev()
+    g = torch.Generator().manual_seed(1000 + seed)
+    topk = int(torch.randint(4, 11, (1,), generator=g))
+    paths = _random_tree(g, topk, 5, int(torch.randint(5, 41, (1,), generator=g)))
+    vocab = int(torch.randint(3, 7, (1,), generator=g))
+    tb_o = ot.generate_tree_buffers(paths, topk=topk)
+    tb = TreeBuffers(paths, topk=topk, device=d)
+    n_rows = 1 + sum(len(s_) for s_ in tb_o.step_nodes)
+    B = 7
+    flat = torch.randint(0, vocab, (B, n_rows, topk), generator=g)
+    root = torch.randint(0, vocab, (B,), generator=g)
+    tgt = torch.randint(0, vocab, (B, tb_o.n_nodes), generator=g)
+    prev = torch.randint(0, 20, (B,), generator=g).to(torch.int32)
+    res, tok_g, cart_g, acc_g = ops.greedy_accept(root.to(d), flat.to(d), tb.tree_indices, tb.retrieve_indices,
+                                                  tgt.to(d), prev.to(d), B=B, want_debug=True)
+    hidden = torch.randn(B, tb_o.n_nodes, 32, generator=g).to(BF)
+    kvc = torch.randn(2, B, 3, 64, 8, generator=g).to(BF)          # [outer, B, inner, cap, hd]
+    kv_g = kvc.to(d).clone()
+    ops.kv_compact(kv_g, B, 3, tb.retrieve_indices, res, prev.to(d))
+    acc_h = ops.gather_accepted(hidden.to(d), tb.retrieve_indices, res, B=B)
+    lens = []
+    for b in range(B):
+        tok, cart = ot.tree_candidates(int(root[b]), flat[b], tb_o)
+        best, alen, nxt, acc = ot.greedy_accept(cart, tgt[b], tb_o)
+        lens.append(alen)
+        assert res[b].tolist() == [best, alen, nxt, int(prev[b]) + alen + 1], (seed, b)
+        assert torch.equal(tok_g[b].cpu(), tok) and torch.equal(cart_g[b].cpu(), cart) and acc_g[b].tolist() == acc.tolist()
+        ref_kv = kvc[:, b].clone()
+        _, ref_h = ot.compact([ref_kv], hidden[b:b + 1], tb_o, best, alen, int(prev[b]))
+        assert torch.equal(kv_g[:, b].cpu(), ref_kv)
+        assert torch.equal(acc_h[b, : alen + 1].cpu(), ref_h[0]) and float(acc_h[b, alen + 1:].abs().sum()) == 0.0
+    assert max(lens) > 0, "tiny vocabularies should accept something"
+
+
 def test_tree_gather_ids():
     from eagle_amd import ops
     from eagle_amd.tree import TreeBuffers
