@@ -144,3 +144,42 @@ def test_topk_generate_shapes_and_chain():
     with torch.no_grad():
         ids2, _, stable2, _ = ot.topk_generate(draft, lm_head, tb, torch.randn(1, 3, 64, generator=g), tokens2, stable)
     assert stable2[0][0].shape[2] == ctx + 3 and ids2.shape == (11, 10)
+
+
+def _random_paths(g, topk, max_depth, max_nodes):
+    paths = {(int(torch.randint(0, topk, (1,), generator=g)),)}
+    while len(paths) < max_nodes:
+        parent = sorted(paths)[int(torch.randint(0, len(paths), (1,), generator=g))]
+        if torch.rand(1, generator=g) < 0.3:
+            paths.add((int(torch.randint(0, topk, (1,), generator=g)),))
+        elif len(parent) < max_depth:
+            paths.add(parent + (int(torch.randint(0, topk, (1,), generator=g)),))
+    return [list(p) for p in paths]          # unsorted on purpose: both builders sort by (len, path)
+
+
+def test_host_tree_buffers_equal_the_oracle_on_random_trees():
+    """The host-side buffers the kernels consume (eagle_amd.tree.TreeBuffers, CPU tensors) against the oracle's, for
+    random prefix-closed trees in both expansion modes: draft-side indices / parent rows / repeat counts / masks and
+    verify-side mask, indices, positions and retrieve table."""
+    from eagle_amd.tree import TreeBuffers
+    for seed in range(12):
+        g = torch.Generator().manual_seed(seed)
+        topk = int(torch.randint(3, 11, (1,), generator=g))
+        paths = _random_paths(g, topk, int(torch.randint(2, 7, (1,), generator=g)), int(torch.randint(3, 50, (1,), generator=g)))
+        for expand in ("wchild", "all"):
+            o = ot.generate_tree_buffers(paths, topk=topk, expand=expand)
+            h = TreeBuffers(paths, topk=topk, expand=expand, device="cpu")
+            assert (h.n_nodes, h.parent, h.depth, h.choice) == (o.n_nodes, o.parent, o.depth, o.choice)
+            assert len(h.steps) == len(o.step_nodes)
+            for d, st in enumerate(h.steps):
+                assert st.nodes == o.step_nodes[d]
+                assert st.tree_indices.tolist() == o.step_tree_indices[d].tolist()
+                assert st.parent_row.tolist() == o.step_parent_row[d].tolist()
+                assert st.repeat_nums == o.step_repeat_nums[d]
+                assert torch.equal(st.attn_mask.float(), o.step_attn_mask[d].float())
+                assert torch.equal(st.attn_mask_u8.float(), o.step_attn_mask[d][0, 0].float())
+            assert torch.equal(h.tree_attn_mask.float(), o.tree_attn_mask.float())
+            assert h.tree_indices.tolist() == o.tree_indices.tolist()
+            assert h.tree_position_ids.tolist() == o.tree_position_ids.tolist()
+            assert h.retrieve_indices.tolist() == o.retrieve_indices.tolist()
+            assert h.flat_row == o.flat_row
