@@ -167,6 +167,16 @@ def test_topk_with_row_lse_from_the_same_pass(rows, V):
     assert torch.allclose(lse, ops.row_lse(xd), rtol=1e-5, atol=1e-4)
 
 
+def test_topk_vocabulary_smaller_than_k():
+    """V < k: the V entries in order, then index -1 / value 0 (the documented contract), bf16 and fp32."""
+    from eagle_amd import ops
+    for dt in (BF, torch.float32):
+        x = torch.tensor([[0.5, -1.0, 3.0, 3.0, float("-inf"), 0.5, 2.0]], dtype=dt)
+        v, i = ops.topk(x.to(dev()), 10)
+        assert i[0].tolist() == [2, 3, 6, 0, 5, 1, 4, -1, -1, -1]
+        assert v[0, :6].tolist() == [3.0, 3.0, 2.0, 0.5, 0.5, -1.0] and v[0, 6].item() == float("-inf") and v[0, 7:].tolist() == [0.0] * 3
+
+
 def test_topk_tie_and_special_values():
     from eagle_amd import ops
     x = torch.zeros(4, 5000, dtype=BF)
