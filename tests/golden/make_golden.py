@@ -18,14 +18,23 @@ g1_tiny_{fp32,bf16}.safetensors   D=64 I=128 H=4 V=100: weights, inputs, eval fo
 g2_real_{fp32,bf16}.safetensors   resources/eagle_config.json dims (D=4096 I=11008 H=32 V=32000),
                                   B=1 L=16; weights are NOT stored: they come from the seed recipe
                                   ``oracle.draft_model.init_weights(dims, seed=1234)``.
-g3_loss_{fp32,bf16}.safetensors   loss block.  eagle/train.py's loss lines (105-124) sit inline in
-                                  ``coach()`` behind a top-level ``import clearml`` (not installed),
-                                  so they cannot be called; this fixture is produced by the op
-                                  sequence in ``oracle.loss.eager_loss`` + autograd and guards the
-                                  oracle and the kernels against drift (it is not an independent pin).
+g3_loss_{fp32,bf16}.safetensors   loss block, produced by EXECUTING THE REFERENCE'S OWN STATEMENTS: eagle/train.py and
+                                  eagle/train_tp.py cannot be imported (top-level ``import clearml``, not installed)
+                                  and the loss lines sit inline in ``coach()``, so the statements that follow
+                                  ``predict = model(...)`` up to ``loss = arguments.v_w * vloss + ...``
+                                  (train.py:106-123, train_tp.py:88-105; the line ranges are asserted) are taken
+                                  out of the parsed file with ``ast``, compiled and run in a namespace holding
+                                  ``torch``, ``arguments``, ``lm_head`` (nn.Linear, bias=False), ``criterion``
+                                  (SmoothL1Loss(reduction="none"), train.py:65), ``batch`` and ``predict``; autograd
+                                  gives dlogits / dpredict.  Both scripts' blocks are run and must agree bit for bit.
+                                  Cases: s (N=2x4, V=1000), m (1x6, V=4099), q (1x4, V=151936; W from a seed recipe,
+                                  not stored); the bf16 file also holds x = train.py under accelerate bf16 mixed
+                                  precision (predict fp32, lm_head / target bf16).
 """
+import ast
 import os
 import sys
+import types
 
 import torch
 from safetensors.torch import save_file
@@ -39,7 +48,6 @@ import transformers  # noqa: E402
 from eagle.llama2 import Llama2Model  # noqa: E402  (the reference)
 
 from oracle.draft_model import DraftDims, init_weights  # noqa: E402
-from oracle.loss import eager_loss  # noqa: E402
 from oracle.tree import generate_tree_buffers  # noqa: E402
 
 
@@ -125,23 +133,96 @@ def g2(dtype, name):
     save_file(out, os.path.join(HERE, name))
 
 
+def ref_loss_block(path, first, last):
+    """The reference's loss statements as a compiled code object: everything after ``predict = model(...)`` up to and
+    including ``loss = arguments.v_w * vloss + arguments.p_w * ploss`` inside ``coach()``."""
+    tree = ast.parse(open(path).read(), filename=path)
+
+    def is_assign_to(st, name):
+        return isinstance(st, ast.Assign) and len(st.targets) == 1 and isinstance(st.targets[0], ast.Name) \
+            and st.targets[0].id == name
+
+    for node in ast.walk(tree):
+        body = getattr(node, "body", None)
+        if not isinstance(body, list):
+            continue
+        for i, st in enumerate(body):
+            if is_assign_to(st, "predict"):
+                block = []
+                for st2 in body[i + 1:]:
+                    block.append(st2)
+                    if is_assign_to(st2, "loss"):
+                        break
+                assert (block[0].lineno, block[-1].end_lineno) == (first, last), (path, block[0].lineno, block[-1].end_lineno)
+                mod = ast.Module(body=block, type_ignores=[])
+                return compile(mod, path, "exec")
+    raise RuntimeError(f"loss block not found in {path}")
+
+
+REF_BLOCKS = None
+
+
+def run_ref_loss(predict, target, W, mask, v_w=1.0, p_w=0.1):
+    """Execute the reference's loss lines (both scripts) on the given tensors; returns the namespace of train.py's run."""
+    global REF_BLOCKS
+    if REF_BLOCKS is None:
+        REF_BLOCKS = [ref_loss_block("/root/reference/eagle/train.py", 106, 123),
+                      ref_loss_block("/root/reference/eagle/train_tp.py", 88, 105)]
+    runs = []
+    for code in REF_BLOCKS:
+        p = predict.detach().clone().requires_grad_(True)
+        lm_head = torch.nn.Linear(W.shape[1], W.shape[0], bias=False, dtype=W.dtype)   # train.py:215-228
+        lm_head.weight.data = W.clone()
+        lm_head.weight.requires_grad_(False)
+        ns = {
+            "torch": torch,
+            "arguments": types.SimpleNamespace(verifier_model_lm_head_dtype=str(W.dtype).split(".")[1], v_w=v_w, p_w=p_w),
+            "lm_head": lm_head,
+            "criterion": torch.nn.SmoothL1Loss(reduction="none"),                        # train.py:65
+            "batch": {"target": target, "loss_mask": mask},
+            "predict": p,
+            "step_correctly_predicted_tokens_count": 0,
+        }
+        exec(code, ns)
+        ns["out_head"].retain_grad()
+        ns["loss"].backward()
+        runs.append(ns)
+    a, b = runs
+    for k in ("target_head", "out_head", "ploss", "vloss", "loss"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["step_correctly_predicted_tokens_count"] == b["step_correctly_predicted_tokens_count"]
+    assert torch.equal(a["out_head"].grad, b["out_head"].grad) and torch.equal(a["predict"].grad, b["predict"].grad)
+    return a
+
+
+def g3_big_weight(V, D, dtype):
+    """Seed recipe of the q case's lm_head (151936 x 32: not stored in the fixture)."""
+    return (torch.randn(V, D, generator=torch.Generator().manual_seed(33)) * 0.3).to(dtype)
+
+
 def g3(dtype, name):
     g = torch.Generator().manual_seed(3)
     out = {}
-    for tag, (B, L, D, V) in {"s": (2, 4, 32, 1000), "m": (1, 6, 64, 4099)}.items():
-        W = (torch.randn(V, D, generator=g) * 0.3).to(dtype)
-        predict = torch.randn(B, L, D, generator=g).to(dtype).requires_grad_(True)
+    cases = {"s": (2, 4, 32, 1000, dtype), "m": (1, 6, 64, 4099, dtype), "q": (1, 4, 32, 151936, dtype)}
+    if dtype == torch.bfloat16:
+        cases["x"] = (2, 4, 32, 1000, torch.float32)        # accelerate mixed precision: predict arrives as fp32
+    for tag, (B, L, D, V, pdtype) in cases.items():
+        W = g3_big_weight(V, D, dtype) if tag == "q" else (torch.randn(V, D, generator=g) * 0.3).to(dtype)
+        predict = torch.randn(B, L, D, generator=g).to(dtype).to(pdtype)
         target = (predict.detach().float() + 0.7 * torch.randn(B, L, D, generator=g)).to(dtype)
         mask = (torch.rand(B, L, generator=g) < 0.7).long()
-        r = eager_loss(predict, target, W, mask, v_w=1.0, p_w=0.1)
-        r["out_logits"].retain_grad()
-        r["loss"].backward()
+        if tag == "q":
+            mask[0, 0] = 1
+        r = run_ref_loss(predict, target, W, mask, v_w=1.0, p_w=0.1)
+        if tag != "q":
+            out[f"{tag}.W"] = c(W)
         out.update({
-            f"{tag}.W": c(W), f"{tag}.predict": c(predict), f"{tag}.target": c(target), f"{tag}.mask": c(mask),
-            f"{tag}.t_logits": c(r["target_logits"]), f"{tag}.o_logits": c(r["out_logits"]),
+            f"{tag}.predict": c(predict), f"{tag}.target": c(target), f"{tag}.mask": c(mask),
+            f"{tag}.t_logits": c(r["target_head"]), f"{tag}.o_logits": c(r["out_head"]),
             f"{tag}.ploss": c(r["ploss"].float().reshape(1)), f"{tag}.vloss": c(r["vloss"].float().reshape(1)),
-            f"{tag}.loss": c(r["loss"].float().reshape(1)), f"{tag}.correct": c(r["correct"].reshape(1)),
-            f"{tag}.dlogits": c(r["out_logits"].grad), f"{tag}.dpredict": c(predict.grad),
+            f"{tag}.loss": c(r["loss"].float().reshape(1)),
+            f"{tag}.correct": torch.tensor([int(r["step_correctly_predicted_tokens_count"])], dtype=torch.int64),
+            f"{tag}.dlogits": c(r["out_head"].grad), f"{tag}.dpredict": c(r["predict"].grad),
         })
     save_file(out, os.path.join(HERE, name))
 

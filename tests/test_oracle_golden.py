@@ -55,14 +55,28 @@ def test_g2_real_dims_bit_exact(golden_dir, tag, dtype):
         assert torch.equal(o2, fx["t.out"])
 
 
+def g3_big_weight(V, D, dtype):
+    """Seed recipe of the q case's lm_head (tests/golden/make_golden.py: 151936 x 32, not stored)."""
+    return (torch.randn(V, D, generator=torch.Generator().manual_seed(33)) * 0.3).to(dtype)
+
+
 @pytest.mark.parametrize("tag,dtype", [("fp32", torch.float32), ("bf16", torch.bfloat16)])
 def test_g3_loss_fixture(golden_dir, tag, dtype):
+    """The fixture holds what the REFERENCE'S OWN loss statements (eagle/train.py:106-123 == eagle/train_tp.py:88-105,
+    ast-extracted and executed by make_golden.py) computed; oracle.loss.eager_loss must match it bit for bit.
+    q = the full Qwen3 vocabulary (N=4, V=151936); x (bf16 file) = train.py under accelerate bf16 mixed precision,
+    where predict reaches the loss as fp32."""
     fx = load_file(os.path.join(golden_dir, f"g3_loss_{tag}.safetensors"))
-    for c in ("s", "m"):
+    cases = ("s", "m", "q") + (("x",) if tag == "bf16" else ())
+    for c in cases:
+        W = g3_big_weight(151936, 32, dtype) if c == "q" else fx[f"{c}.W"]
         predict = fx[f"{c}.predict"].clone().requires_grad_(True)
-        r = ol.eager_loss(predict, fx[f"{c}.target"], fx[f"{c}.W"], fx[f"{c}.mask"])
+        r = ol.eager_loss(predict, fx[f"{c}.target"], W, fx[f"{c}.mask"])
         r["out_logits"].retain_grad()
         r["loss"].backward()
+        assert torch.equal(r["target_logits"], fx[f"{c}.t_logits"]) and torch.equal(r["out_logits"], fx[f"{c}.o_logits"])
+        assert torch.equal(r["ploss"].float().reshape(1), fx[f"{c}.ploss"])
+        assert torch.equal(r["vloss"].float().reshape(1), fx[f"{c}.vloss"])
         assert torch.equal(r["loss"].float().reshape(1), fx[f"{c}.loss"])
         assert torch.equal(r["correct"].reshape(1), fx[f"{c}.correct"])
         assert torch.equal(r["out_logits"].grad, fx[f"{c}.dlogits"])
