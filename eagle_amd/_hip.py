@@ -46,6 +46,7 @@ SIGNATURES = {
     "eagle_rope_qk_bf16": (I, [P, L, P, P, P, I, L, I, I, I, I, P]),
     "eagle_topk_workspace_bytes": (L, [I, I, I]),
     "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P, L, P]),
+    "eagle_topk_vocab_noalloc": (I, [P, L, I, I, I, I, P, P, P, L, P]),
     "eagle_topk_lse_vocab": (I, [P, L, I, I, I, P, P, P, P, P]),
     "eagle_tree_gather_ids": (I, [P, L, P, I, P, I, P]),
     "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, P, P, P, P, I, P, P, P, I, P]),

@@ -289,3 +289,33 @@ extern "C" int eagle_topk_lse_vocab(const void* logits, int64_t ld, int rows, in
   if (!lse_out) return EAGLE_ERR_ARG;
   return topk_launch(logits, ld, 0, rows, V, k, out_idx, out_val, workspace, nullptr, 0, lse_out, stream);
 }
+
+// ---- the entry point that allocates nothing (no counterpart in the reference) ----
+// For callers that cannot call hipMalloc or hand in a workspace (code under HIP graph capture, tight serving loops,
+// harnesses that forbid allocation): the stage-1 candidate buffer is a file-scope device array.  Every GPU the library
+// runs on holds its own 2 MiB copy until the process ends.  The array's NAME is a host-side stand-in, not a device
+// address: host code only ever uses the per-device address hipGetSymbolAddress returned.
+#define TK_SCRATCH_BYTES (2 << 20)
+#define TK_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[TK_SCRATCH_BYTES];
+static void* g_tk_scratch_ptr[TK_MAX_DEVICES];          // per device: each GPU has the array at its own address
+
+// Same contract as eagle_topk_vocab (bf16 / fp32 logits, optional ring cursor) without the workspace argument.
+// Limit: eagle_topk_workspace_bytes(rows, V, k) <= 2 MiB (e.g. 159 rows of a 151936-entry vocabulary at k = 10),
+// larger problems return EAGLE_ERR_SHAPE.  All calls on one GPU share that GPU's array: calls that overlap on one
+// GPU (two streams, two threads) race.  Nothing in the array has to start at zero: stage 1 writes every candidate slot
+// stage 2 reads, so a call never sees the previous call's contents.  The first call on a device resolves the array's
+// device address (hipGetSymbolAddress: not capturable -- make one call per device before capturing a graph).
+extern "C" int eagle_topk_vocab_noalloc(const void* logits, int64_t ld, int dtype, int rows, int V, int k, int64_t* out_idx,
+                                        void* out_val, const int64_t* block_index, int64_t block_rows, hipStream_t stream) {
+  if (rows < 1 || V < 1 || k < 1 || k > TK_MAXK) return EAGLE_ERR_SHAPE;
+  if (eagle_topk_workspace_bytes(rows, V, k) > (int64_t)TK_SCRATCH_BYTES) return EAGLE_ERR_SHAPE;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TK_MAX_DEVICES) return EAGLE_ERR_ARG;
+  void* p = __atomic_load_n(&g_tk_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!p) {
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return EAGLE_ERR_LAUNCH;
+    __atomic_store_n(&g_tk_scratch_ptr[dev], p, __ATOMIC_RELEASE);   // same value whichever thread stores it
+  }
+  return topk_launch(logits, ld, dtype, rows, V, k, out_idx, out_val, p, block_index, block_rows, nullptr, stream);
+}

@@ -153,6 +153,17 @@ int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V,
 int eagle_topk_lse_vocab(const void* logits, int64_t ld, int rows, int V, int k, int64_t* out_idx, void* out_val,
                          float* lse_out, void* workspace, eagle_stream_t stream);
 
+/* NO COUNTERPART IN THE REFERENCE.  eagle_topk_vocab for callers that cannot allocate or hand in a workspace (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): same contract, no workspace argument -- the
+ * stage-1 candidates live in a 2 MiB device array inside the library (one copy per GPU, held until the process ends).
+ * Limit: eagle_topk_workspace_bytes(rows, V, k) <= 2 MiB (159 rows of a 151936-entry vocabulary at k = 10), beyond it
+ * EAGLE_ERR_SHAPE.  Calls no hipMalloc / hipFree / allocating routine.  All calls on one GPU share that GPU's array, so
+ * calls that overlap on one GPU race; nothing in it has to start at zero (every slot read was written by the same call).
+ * `stream` must belong to the current device; the first call on a device resolves the array's address and is not
+ * capturable -- make one call per device before capturing a graph. */
+int eagle_topk_vocab_noalloc(const void* logits, int64_t ld, int dtype, int rows, int V, int k, int64_t* out_idx,
+                             void* out_val, const int64_t* block_index, int64_t block_rows, eagle_stream_t stream);
+
 /* Static-tree kernels (Llama2Model.init_tree / tree_mask hooks,
  * eagle/llama2.py:453-458 -- the algorithm itself is the upstream EAGLE-1 one). */
 /* out_ids[b][j] = flat_ids[b][tree_idx[j]]: draft tokens of one expansion step. */
