@@ -30,7 +30,6 @@ class HipKernelError(RuntimeError):
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, I, L, F, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
-    "eagle_skinny_resident_weights": (I, [P, I]),
     "eagle_gemm_nt_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, P]),
     "eagle_gemm_nt_splitk_workspace_bytes": (L, [I, I, I]),
     "eagle_gemm_nt_splitk_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, P, P]),
@@ -48,6 +47,8 @@ SIGNATURES = {
     "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P, L, P]),
     "eagle_topk_vocab_noalloc": (I, [P, L, I, I, I, I, P, P, P, L, P]),
     "eagle_topk_lse_vocab": (I, [P, L, I, I, I, P, P, P, P, P]),
+    "eagle_tree_layout": (I, [P, I, I, I, I, P]),
+    "eagle_tree_build": (I, [P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),
     "eagle_tree_gather_ids": (I, [P, L, P, I, P, I, P]),
     "eagle_greedy_accept": (I, [P, P, L, P, I, P, I, I, P, P, P, P, P, P, P, P, P, P, I, P, P, P, I, P]),
     "eagle_kv_compact_bf16": (I, [P, L, L, I, I, I, P, I, P, P, I, P, P]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     "eagle_scale_bf16": (I, [P, L, P, P]),
     "eagle_add_f32_bf16": (I, [P, P, P, L, P]),
     "eagle_make_eagle_input_bf16": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "eagle_debug_set_gemm8": (None, [I]),
+    "eagle_debug_set_skinny_variant": (None, [I, I, I]),
 }
 
 _lib = None

@@ -88,3 +88,4 @@ def load_trainer_state(trainer, ckpt_dir: Union[str, os.PathLike]) -> None:
     trainer.v.copy_(v)
     trainer.step_count, trainer.sched_step = int(meta["step_count"]), int(meta["sched_step"])
     trainer._pversion += 1          # the weights were (re)loaded too: drop the cached transposed copies
+    trainer.model.invalidate_weight_caches()

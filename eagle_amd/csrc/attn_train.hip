@@ -14,50 +14,11 @@
 // 16*(j>>2) + 4g + (j&3)); the other operand of that product is an LDS tile stored transposed
 // with the same slot order.
 #include "common.h"
-#include <stdlib.h>
 
 #define AT_THREADS 256
 #define AT_HD 128
-#define AT_QB 64      // rows per workgroup (16 per wave)
-#define AT_KB 32      // streamed rows per step
-#define AT_LDR (AT_HD + 8)   // row-major tile row (elements): 272 B, conflict-free b128 fragment reads
-#define AT_LDT (AT_KB + 8)   // transposed tile row (elements): 80 B
 #define LOG2E 1.4426950408889634f
 
-__device__ __forceinline__ int at_slot(int r) {  // row 0..31 of a streamed tile -> k-slot of the transposed image
-  const int t = r >> 4, w = r & 15;
-  return (w >> 2) * 8 + (w & 3) + 4 * t;
-}
-
-// stage a [32][128] bf16 tile (rows r0.., stride ld) row-major and/or transposed into LDS
-__device__ __forceinline__ void at_load2(const bf16_t* base, int64_t ld, int r0, int nrows, int tid, uint4* v) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = i * AT_THREADS + tid;      // 16-byte chunk id: row = c/16, col8 = c%16
-    const int row = c >> 4, col = (c & 15) * 8;
-    v[i] = (r0 + row < nrows) ? *reinterpret_cast<const uint4*>(base + (int64_t)(r0 + row) * ld + col) : make_uint4(0, 0, 0, 0);
-  }
-}
-__device__ __forceinline__ void at_store_rm(bf16_t* tile, int tid, const uint4* v) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = i * AT_THREADS + tid;
-    *reinterpret_cast<uint4*>(tile + (c >> 4) * AT_LDR + (c & 15) * 8) = v[i];
-  }
-}
-__device__ __forceinline__ void at_store_tr(bf16_t* tile, int tid, const uint4* v) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = i * AT_THREADS + tid;
-    const int slot = at_slot(c >> 4), col = (c & 15) * 8;
-    const uint32_t* u = reinterpret_cast<const uint32_t*>(&v[i]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      tile[(col + 2 * j) * AT_LDT + slot] = (bf16_t)(u[j] & 0xffff);
-      tile[(col + 2 * j + 1) * AT_LDT + slot] = (bf16_t)(u[j] >> 16);
-    }
-  }
-}
 __device__ __forceinline__ bf16x8 pack_frag(const f32x4& a, const f32x4& b) {
   bf16x8 r;
   r[0] = (__bf16)a[0]; r[1] = (__bf16)a[1]; r[2] = (__bf16)a[2]; r[3] = (__bf16)a[3];
@@ -75,96 +36,7 @@ struct AttnTrainArgs {
   int B, L, H;
   float scale2;                        // log2(e)/sqrt(hd)
   float scale;                         // 1/sqrt(hd)
-  int dbg;                             // timing experiments only (EAGLE_ATTN_DBG): wrong results when non-zero
 };
-
-// ------------------------------------------------------------------ forward
-__global__ __launch_bounds__(AT_THREADS) void attn_train_fwd_kernel(AttnTrainArgs p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[AT_KB * AT_LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[AT_HD * AT_LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-  const int qb = (gridDim.x - 1 - blockIdx.x), h = blockIdx.y, b = blockIdx.z;   // heaviest (last) query blocks first
-  const int D = p.H * AT_HD, L = p.L;
-  const bf16_t* base = p.qkv + (int64_t)b * L * p.ld + h * AT_HD;
-  const bf16_t* kbase = base + D;
-  const bf16_t* vbase = base + 2 * D;
-  const int q0 = qb * AT_QB + wave * 16;
-  const int qi = q0 + r16;                       // this lane's query (as MFMA column)
-  bf16x8 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    qf[s] = qi < L ? *reinterpret_cast<const bf16x8*>(base + (int64_t)qi * p.ld + 32 * s + 8 * g) : z;
-  }
-  f32x4 o[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m = -INFINITY, lsum = 0.f;
-  const int kend = min(L, qb * AT_QB + AT_QB);   // causal: keys < end of this query block
-  uint4 kv[2], vv[2];
-  at_load2(kbase, p.ld, 0, L, tid, kv);
-  at_load2(vbase, p.ld, 0, L, tid, vv);
-  for (int k0 = 0; k0 < kend; k0 += AT_KB) {
-    __syncthreads();                 // previous tile fully consumed
-    at_store_rm(Ks, tid, kv);
-    at_store_tr(Vt, tid, vv);
-    __syncthreads();
-    if (k0 + AT_KB < kend) {         // prefetch the next tile into registers
-      at_load2(kbase, p.ld, k0 + AT_KB, L, tid, kv);
-      at_load2(vbase, p.ld, k0 + AT_KB, L, tid, vv);
-    }
-    if (k0 > q0 + 15) continue;      // wave-uniform: whole tile above this wave's diagonal
-    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(Ks + r16 * AT_LDR + 32 * s + 8 * g);
-      const bf16x8 kb = *reinterpret_cast<const bf16x8*>(Ks + (16 + r16) * AT_LDR + 32 * s + 8 * g);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[s], s1, 0, 0, 0);
-    }
-    float x[8];
-    float mx = m;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ka = k0 + 4 * g + r, kb = ka + 16;
-      x[r] = (ka <= qi && ka < L) ? s0[r] * p.scale2 : -INFINITY;
-      x[4 + r] = (kb <= qi && kb < L) ? s1[r] * p.scale2 : -INFINITY;
-      mx = fmaxf(mx, fmaxf(x[r], x[4 + r]));
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float alpha = (m > -INFINITY) ? exp2f(m - mx) : 0.f;
-    f32x4 p0, p1;
-    float ps = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      p0[r] = (mx > -INFINITY) ? exp2f(x[r] - mx) : 0.f;
-      p1[r] = (mx > -INFINITY) ? exp2f(x[4 + r] - mx) : 0.f;
-      ps += p0[r] + p1[r];
-    }
-    lsum = lsum * alpha + ps;
-    m = mx;
-    const bf16x8 pf = pack_frag(p0, p1);
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      o[dt] *= alpha;
-      const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vt + (dt * 16 + r16) * AT_LDT + 8 * g);
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[dt], 0, 0, 0);
-    }
-  }
-  lsum += __shfl_xor(lsum, 16, 64);
-  lsum += __shfl_xor(lsum, 32, 64);
-  if (qi < L) {
-    const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-    bf16_t* orow = p.out + ((int64_t)b * L + qi) * p.ldo + h * AT_HD;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const uint2 w = make_uint2(pack2bf(o[dt][0] * inv, o[dt][1] * inv), pack2bf(o[dt][2] * inv, o[dt][3] * inv));
-      *reinterpret_cast<uint2*>(orow + dt * 16 + 4 * g) = w;
-    }
-    if (g == 0) p.lse[((int64_t)b * p.H + h) * L + qi] = m + log2f(lsum);
-  }
-}
 
 // Workgroup -> (pair index, head, batch) for the second-generation kernels: a 1-D grid whose ids
 // b, b+8, ... share an XCD (round-robin dispatch) is remapped so that every XCD owns a CONTIGUOUS
@@ -254,10 +126,10 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd2_kernel(AttnTrainAr
   const int tq = (lane & 15) >> 2, tp = lane & 3;
   for (int t = 0; t < nt; ++t) {
     const int k0 = t * A2_KB;
-    if (!(p.dbg & 1)) stage(k0 + A2_KB, (t + 1) & 1);   // unconditional (past the end: clamped rows, never read)
+    stage(k0 + A2_KB, (t + 1) & 1);   // unconditional (past the end: clamped rows, never read)
     const char* Kt = &lds[t & 1][0][0];
     const char* Vt = &lds[t & 1][1][0];
-    if (k0 <= qw + 31 && !(p.dbg & 8)) {         // wave-uniform: at least one visible key in this tile
+    if (k0 <= qw + 31) {         // wave-uniform: at least one visible key in this tile
       f32x4 sc[4][2];
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt) { sc[kt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[kt][1] = sc[kt][0]; }
@@ -295,8 +167,6 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd2_kernel(AttnTrainAr
       __builtin_amdgcn_sched_barrier(0);
       const bool need_mask = (k0 + A2_KB - 1 > qw) || (k0 + A2_KB > L);   // wave-uniform
       bf16x8 pf[2][2];
-      if (p.dbg & 2) { pf[0][0] = pack_frag(sc[0][0], sc[1][0]); pf[0][1] = pack_frag(sc[2][0], sc[3][0]); pf[1][0] = pack_frag(sc[0][1], sc[1][1]); pf[1][1] = pack_frag(sc[2][1], sc[3][1]); }
-      else
 #pragma unroll
       for (int qg = 0; qg < 2; ++qg) {
         // VALU diet (this loop, not the MFMAs, bounds the kernel): the running maximum is kept on the
@@ -341,7 +211,6 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd2_kernel(AttnTrainAr
         pf[qg][0] = pack_frag(sc[0][qg], sc[1][qg]);
         pf[qg][1] = pack_frag(sc[2][qg], sc[3][qg]);
       }
-      if (!(p.dbg & 4))
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -388,172 +257,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   if (lane == 0) {
     const int64_t bb = row / L, i = row - bb * L;
     delta[(bb * H + h) * L + i] = s;
-  }
-}
-
-// ------------------------------------------------------------------ backward: dQ (query stationary)
-__global__ __launch_bounds__(AT_THREADS) void attn_train_dq_kernel(AttnTrainArgs p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[AT_KB * AT_LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[AT_KB * AT_LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t Kt[AT_HD * AT_LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-  const int qb = (gridDim.x - 1 - blockIdx.x), h = blockIdx.y, b = blockIdx.z;
-  const int D = p.H * AT_HD, L = p.L;
-  const bf16_t* base = p.qkv + (int64_t)b * L * p.ld + h * AT_HD;
-  const bf16_t* kbase = base + D;
-  const bf16_t* vbase = base + 2 * D;
-  const int q0 = qb * AT_QB + wave * 16;
-  const int qi = q0 + r16;
-  bf16x8 qf[4], dof[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    qf[s] = qi < L ? *reinterpret_cast<const bf16x8*>(base + (int64_t)qi * p.ld + 32 * s + 8 * g) : z;
-    dof[s] = qi < L ? *reinterpret_cast<const bf16x8*>(p.dout + ((int64_t)b * L + qi) * p.lddo + h * AT_HD + 32 * s + 8 * g) : z;
-  }
-  const float lse = qi < L ? p.lse[((int64_t)b * p.H + h) * L + qi] : 0.f;
-  const float dl = qi < L ? p.delta[((int64_t)b * p.H + h) * L + qi] : 0.f;
-  f32x4 dq[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int kend = min(L, qb * AT_QB + AT_QB);
-  uint4 kv[2], vv[2];
-  at_load2(kbase, p.ld, 0, L, tid, kv);
-  at_load2(vbase, p.ld, 0, L, tid, vv);
-  for (int k0 = 0; k0 < kend; k0 += AT_KB) {
-    __syncthreads();
-    at_store_rm(Ks, tid, kv);
-    at_store_tr(Kt, tid, kv);
-    at_store_rm(Vs, tid, vv);
-    __syncthreads();
-    if (k0 + AT_KB < kend) {
-      at_load2(kbase, p.ld, k0 + AT_KB, L, tid, kv);
-      at_load2(vbase, p.ld, k0 + AT_KB, L, tid, vv);
-    }
-    if (k0 > q0 + 15) continue;
-    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(Ks + r16 * AT_LDR + 32 * s + 8 * g);
-      const bf16x8 kb = *reinterpret_cast<const bf16x8*>(Ks + (16 + r16) * AT_LDR + 32 * s + 8 * g);
-      const bf16x8 va = *reinterpret_cast<const bf16x8*>(Vs + r16 * AT_LDR + 32 * s + 8 * g);
-      const bf16x8 vb = *reinterpret_cast<const bf16x8*>(Vs + (16 + r16) * AT_LDR + 32 * s + 8 * g);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[s], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kb, qf[s], s1, 0, 0, 0);
-      d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[s], d0, 0, 0, 0);
-      d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vb, dof[s], d1, 0, 0, 0);
-    }
-    f32x4 ds0, ds1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ka = k0 + 4 * g + r, kb = ka + 16;
-      const float pa = (ka <= qi && ka < L && qi < L) ? exp2f(s0[r] * p.scale2 - lse) : 0.f;
-      const float pb = (kb <= qi && kb < L && qi < L) ? exp2f(s1[r] * p.scale2 - lse) : 0.f;
-      ds0[r] = pa * (d0[r] - dl);
-      ds1[r] = pb * (d1[r] - dl);
-    }
-    const bf16x8 dsf = pack_frag(ds0, ds1);
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const bf16x8 kt = *reinterpret_cast<const bf16x8*>(Kt + (dt * 16 + r16) * AT_LDT + 8 * g);
-      dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsf, dq[dt], 0, 0, 0);
-    }
-  }
-  if (qi < L) {
-    bf16_t* drow = p.dqkv + ((int64_t)b * L + qi) * p.lddq + h * AT_HD;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const uint2 w = make_uint2(pack2bf(dq[dt][0] * p.scale, dq[dt][1] * p.scale), pack2bf(dq[dt][2] * p.scale, dq[dt][3] * p.scale));
-      *reinterpret_cast<uint2*>(drow + dt * 16 + 4 * g) = w;
-    }
-  }
-}
-
-// ------------------------------------------------------------------ backward: dK, dV (key stationary)
-__global__ __launch_bounds__(AT_THREADS) void attn_train_dkv_kernel(AttnTrainArgs p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[AT_KB * AT_LDR];
-  __shared__ __attribute__((aligned(16))) bf16_t Os[AT_KB * AT_LDR];   // dO row-major
-  __shared__ __attribute__((aligned(16))) bf16_t Qt[AT_HD * AT_LDT];
-  __shared__ __attribute__((aligned(16))) bf16_t Ot[AT_HD * AT_LDT];   // dO transposed
-  __shared__ float lse_s[AT_KB], dl_s[AT_KB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
-  const int kb_ = blockIdx.x, h = blockIdx.y, b = blockIdx.z;           // key block 0 is the heaviest: first
-  const int D = p.H * AT_HD, L = p.L;
-  const bf16_t* base = p.qkv + (int64_t)b * L * p.ld + h * AT_HD;
-  const bf16_t* dobase = p.dout + (int64_t)b * L * p.lddo + h * AT_HD;
-  const int k0w = kb_ * AT_QB + wave * 16;
-  const int ki = k0w + r16;                       // this lane's key (as MFMA column)
-  bf16x8 kf[4], vf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    kf[s] = ki < L ? *reinterpret_cast<const bf16x8*>(base + D + (int64_t)ki * p.ld + 32 * s + 8 * g) : z;
-    vf[s] = ki < L ? *reinterpret_cast<const bf16x8*>(base + 2 * D + (int64_t)ki * p.ld + 32 * s + 8 * g) : z;
-  }
-  f32x4 dk[8], dv[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = dk[i]; }
-  const int qstart = (kb_ * AT_QB / AT_KB) * AT_KB;      // causal: queries >= first key of the block
-  uint4 qv[2], ov[2];
-  at_load2(base, p.ld, qstart, L, tid, qv);
-  at_load2(dobase, p.lddo, qstart, L, tid, ov);
-  for (int q0 = qstart; q0 < L; q0 += AT_KB) {
-    __syncthreads();
-    at_store_rm(Qs, tid, qv);
-    at_store_tr(Qt, tid, qv);
-    at_store_rm(Os, tid, ov);
-    at_store_tr(Ot, tid, ov);
-    if (tid < AT_KB) {
-      const int qi = q0 + tid;
-      lse_s[tid] = qi < L ? p.lse[((int64_t)b * p.H + h) * L + qi] : 0.f;
-      dl_s[tid] = qi < L ? p.delta[((int64_t)b * p.H + h) * L + qi] : 0.f;
-    }
-    __syncthreads();
-    if (q0 + AT_KB < L) {
-      at_load2(base, p.ld, q0 + AT_KB, L, tid, qv);
-      at_load2(dobase, p.lddo, q0 + AT_KB, L, tid, ov);
-    }
-    if (q0 + AT_KB - 1 < k0w) continue;            // wave-uniform: all queries of the tile precede this wave's keys
-    f32x4 s0 = (f32x4){0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + r16 * AT_LDR + 32 * s + 8 * g);
-      const bf16x8 qb2 = *reinterpret_cast<const bf16x8*>(Qs + (16 + r16) * AT_LDR + 32 * s + 8 * g);
-      const bf16x8 oa = *reinterpret_cast<const bf16x8*>(Os + r16 * AT_LDR + 32 * s + 8 * g);
-      const bf16x8 ob = *reinterpret_cast<const bf16x8*>(Os + (16 + r16) * AT_LDR + 32 * s + 8 * g);
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[s], s0, 0, 0, 0);     // S[q][key]: rows = queries
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qb2, kf[s], s1, 0, 0, 0);
-      d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(oa, vf[s], d0, 0, 0, 0);     // dP[q][key] = dO . V^T
-      d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ob, vf[s], d1, 0, 0, 0);
-    }
-    f32x4 p0, p1, ds0, ds1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ra = 4 * g + r, rb = ra + 16;     // query rows inside the tile
-      const int qa = q0 + ra, qb2 = q0 + rb;
-      p0[r] = (ki <= qa && qa < L && ki < L) ? exp2f(s0[r] * p.scale2 - lse_s[ra]) : 0.f;
-      p1[r] = (ki <= qb2 && qb2 < L && ki < L) ? exp2f(s1[r] * p.scale2 - lse_s[rb]) : 0.f;
-      ds0[r] = p0[r] * (d0[r] - dl_s[ra]);
-      ds1[r] = p1[r] * (d1[r] - dl_s[rb]);
-    }
-    const bf16x8 pf = pack_frag(p0, p1), dsf = pack_frag(ds0, ds1);
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      const bf16x8 ot = *reinterpret_cast<const bf16x8*>(Ot + (dt * 16 + r16) * AT_LDT + 8 * g);
-      const bf16x8 qt = *reinterpret_cast<const bf16x8*>(Qt + (dt * 16 + r16) * AT_LDT + 8 * g);
-      dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, pf, dv[dt], 0, 0, 0);
-      dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsf, dk[dt], 0, 0, 0);
-    }
-  }
-  if (ki < L) {
-    bf16_t* drow = p.dqkv + ((int64_t)b * L + ki) * p.lddq + h * AT_HD;
-#pragma unroll
-    for (int dt = 0; dt < 8; ++dt) {
-      *reinterpret_cast<uint2*>(drow + D + dt * 16 + 4 * g) =
-          make_uint2(pack2bf(dk[dt][0] * p.scale, dk[dt][1] * p.scale), pack2bf(dk[dt][2] * p.scale, dk[dt][3] * p.scale));
-      *reinterpret_cast<uint2*>(drow + 2 * D + dt * 16 + 4 * g) =
-          make_uint2(pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3]));
-    }
   }
 }
 
@@ -895,7 +598,6 @@ extern "C" int eagle_rope_qk_bf16(void* qkv, int64_t ld, const int64_t* position
   return eagle_check_launch();
 }
 
-static int g_attn_dbg = 0;
 extern "C" int eagle_attn_train_fwd_bf16(const void* qkv, int64_t ld, void* out, int64_t ldo, float* lse, int B, int L, int H,
                                          int hd, hipStream_t stream) {
   int rc = at_check(qkv, ld, B, L, H, hd);
@@ -904,12 +606,7 @@ extern "C" int eagle_attn_train_fwd_bf16(const void* qkv, int64_t ld, void* out,
   AttnTrainArgs a = {};
   a.qkv = (const bf16_t*)qkv; a.ld = ld; a.out = (bf16_t*)out; a.ldo = ldo; a.lse = lse;
   a.B = B; a.L = L; a.H = H; a.scale = 1.0f / sqrtf((float)hd); a.scale2 = a.scale * LOG2E;
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("EAGLE_ATTN_FWD"); v = e ? atoi(e) : 2; const char* d = getenv("EAGLE_ATTN_DBG"); g_attn_dbg = d ? atoi(d) : 0; }
-  a.dbg = g_attn_dbg;
-  if (v == 2) hipLaunchKernelGGL(attn_train_fwd2_kernel<true>, dim3(((L + A2_QB - 1) / A2_QB + 1) / 2 * H * B), dim3(AT_THREADS), 0, stream, a);
-  else if (v == 3) hipLaunchKernelGGL(attn_train_fwd2_kernel<false>, dim3((L + A2_QB - 1) / A2_QB * H * B), dim3(AT_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((L + AT_QB - 1) / AT_QB, H, B), dim3(AT_THREADS), 0, stream, a);
+  hipLaunchKernelGGL(attn_train_fwd2_kernel<true>, dim3(((L + A2_QB - 1) / A2_QB + 1) / 2 * H * B), dim3(AT_THREADS), 0, stream, a);
   return eagle_check_launch();
 }
 
@@ -929,20 +626,10 @@ extern "C" int eagle_attn_train_bwd_bf16(const void* qkv, int64_t ld, const void
   a.qkv = (const bf16_t*)qkv; a.ld = ld; a.lse = (float*)lse; a.dout = (const bf16_t*)dout; a.lddo = lddo; a.delta = delta_ws;
   a.dqkv = (bf16_t*)dqkv; a.lddq = lddq; a.B = B; a.L = L; a.H = H;
   a.scale = 1.0f / sqrtf((float)hd); a.scale2 = a.scale * LOG2E;
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("EAGLE_ATTN_BWD"); v = e ? atoi(e) : 2; }
-  if (v == 2) {
-    const dim3 grid2(((L + A2_QB - 1) / A2_QB + 1) / 2 * H * B);
-    hipLaunchKernelGGL(attn_train_dq2_kernel, grid2, dim3(AT_THREADS), 0, stream, a);
-    rc = eagle_check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL(attn_train_dkv2_kernel, grid2, dim3(AT_THREADS), 0, stream, a);
-    return eagle_check_launch();
-  }
-  const dim3 grid((L + AT_QB - 1) / AT_QB, H, B);
-  hipLaunchKernelGGL(attn_train_dq_kernel, grid, dim3(AT_THREADS), 0, stream, a);
+  const dim3 grid2(((L + A2_QB - 1) / A2_QB + 1) / 2 * H * B);
+  hipLaunchKernelGGL(attn_train_dq2_kernel, grid2, dim3(AT_THREADS), 0, stream, a);
   rc = eagle_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_train_dkv_kernel, grid, dim3(AT_THREADS), 0, stream, a);
+  hipLaunchKernelGGL(attn_train_dkv2_kernel, grid2, dim3(AT_THREADS), 0, stream, a);
   return eagle_check_launch();
 }

@@ -155,10 +155,9 @@ static inline bool gm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                           const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
                           void* workspace, hipStream_t stream);
-static int g_gemm8_mode = -1;   // 0: never, 1: whenever legal, 2: by shape (default); EAGLE_GEMM8 overrides
+static int g_gemm8_mode = 2;    // 0: never, 1: whenever legal, 2: by shape (default); eagle_debug_set_gemm8
 extern "C" void eagle_debug_set_gemm8(int mode) { g_gemm8_mode = mode; }
 static bool use_gemm8(int M, int N, int K) {
-  if (g_gemm8_mode < 0) { const char* e = getenv("EAGLE_GEMM8"); g_gemm8_mode = e ? atoi(e) : 2; }
   if (g_gemm8_mode == 0 || K < 2 * GM_BK) return false;
   if (g_gemm8_mode == 1) return true;
   // decode batches (a row tile that is mostly padding) stream the weights once whatever the tile: the 128x128

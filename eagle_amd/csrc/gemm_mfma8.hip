@@ -413,11 +413,6 @@ __global__ __launch_bounds__(256) void gemm8_reduce_kernel(Gemm8Args p) {
   }
 }
 
-static int g_g8_gm = -1;           // EAGLE_GEMM8_GM: row tiles per group (0 = all rows, the plain column-major order)
-extern "C" void eagle_debug_set_gemm8_gm(int gm) { g_g8_gm = gm; }
-static int g_g8_pingpong = -1;     // EAGLE_GEMM8_PINGPONG=0 selects the in-phase schedule (A/B measurements)
-extern "C" void eagle_debug_set_gemm8_pingpong(int on) { g_g8_pingpong = on; }
-
 // Called by eagle_gemm_nt_bf16 (gemm_mfma.hip) after its argument checks.
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                           const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
@@ -435,24 +430,8 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
   a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = (N + G8_BN - 1) / G8_BN;
-  if (g_g8_gm < 0) { const char* e = getenv("EAGLE_GEMM8_GM"); g_g8_gm = e ? atoi(e) : 8; }
-  a.gm = (g_g8_gm <= 0 || g_g8_gm > a.tiles_m) ? a.tiles_m : g_g8_gm;
-  if (g_g8_pingpong < 0) { const char* e = getenv("EAGLE_GEMM8_PINGPONG"); g_g8_pingpong = e ? atoi(e) : 1; }
-  if (g_g8_pingpong >= 16) {      // timing experiments (tools/gemm_bench.py): 16 + DBG bits
-    const dim3 gr(a.tiles_m * a.tiles_n * a.ksplit), bl(G8_THREADS);
-    switch (g_g8_pingpong - 16) {
-      case 1: hipLaunchKernelGGL((gemm_nt8_kernel<true, 1>), gr, bl, 0, stream, a); break;
-      case 2: hipLaunchKernelGGL((gemm_nt8_kernel<true, 2>), gr, bl, 0, stream, a); break;
-      case 3: hipLaunchKernelGGL((gemm_nt8_kernel<true, 3>), gr, bl, 0, stream, a); break;
-      case 7: hipLaunchKernelGGL((gemm_nt8_kernel<true, 7>), gr, bl, 0, stream, a); break;
-      case 8: hipLaunchKernelGGL((gemm_nt8_kernel<true, 8>), gr, bl, 0, stream, a); break;
-      case 16: hipLaunchKernelGGL((gemm_nt8_kernel<true, 16>), gr, bl, 0, stream, a); break;
-      case 24: hipLaunchKernelGGL((gemm_nt8_kernel<true, 24>), gr, bl, 0, stream, a); break;
-      case 64: hipLaunchKernelGGL((gemm_nt8_kernel<true, 64>), gr, bl, 0, stream, a); break;
-      default: return EAGLE_ERR_ARG;
-    }
-  } else if (g_g8_pingpong) hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
-  else hipLaunchKernelGGL(gemm_nt8_kernel<false>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
+  a.gm = a.tiles_m < 8 ? a.tiles_m : 8;             // row tiles per group of the grouped tile order
+  hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
   int rc = eagle_check_launch();
   if (rc || a.ksplit == 1) return rc;
   const int64_t q4 = (int64_t)M * ((N + 3) / 4);

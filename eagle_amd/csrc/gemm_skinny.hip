@@ -15,7 +15,6 @@
 //   * the activation row can be the concatenation of two gathered sources:
 //     fc(cat(embed_tokens[ids], hidden[parent_row]))  (eagle/llama2.py:515, :542).
 #include "common.h"
-#include <stdlib.h>
 
 #define SK_WAVES 8
 #define EPI_LINEAR 0     // (+bias) (+residual)
@@ -30,6 +29,7 @@ struct SkinnyArgs {
   const bf16_t* bias; const bf16_t* res; int64_t ldr;
   bf16_t* out; int64_t ldo;
   int M, N, K;
+  bool nt;                                               // host-side only: stream W with non-temporal loads
 };
 
 template <int RT, int MT, int EPI>
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   }
 }
 
-static int g_skinny_variant = -1;   // -1: read EAGLE_SKINNY_VARIANT once; 0: tile kernel, 1: streaming kernel
+static int g_skinny_variant = 3;    // 3: per-shape choice (default); 0: tile kernel, 1: streaming kernel, 2: register-resident x where legal
 static int g_sk_blocks_per_cu = 2;
 static int g_sk_min_rows = 16;
 extern "C" void eagle_debug_set_skinny_variant(int v, int blocks_per_cu, int min_rows) {
@@ -575,13 +575,7 @@ extern "C" void eagle_debug_set_skinny_variant(int v, int blocks_per_cu, int min
   if (blocks_per_cu > 0) g_sk_blocks_per_cu = blocks_per_cu;
   if (min_rows > 0) g_sk_min_rows = min_rows;
 }
-static int skinny_variant() {
-  if (g_skinny_variant < 0) {
-    const char* e = getenv("EAGLE_SKINNY_VARIANT");
-    g_skinny_variant = e ? atoi(e) : 3;
-  }
-  return g_skinny_variant;
-}
+static int skinny_variant() { return g_skinny_variant; }
 static int sk_num_cus() {
   static int n = 0;
   if (!n) {
@@ -595,24 +589,12 @@ static int sk_num_cus() {
 
 // Cache policy of the weight stream.  A draft forward streams more weight bytes (734 MB, Llama-2-7B dims)
 // than the 256 MB Infinity Cache holds, five times per cycle: with one policy for all of them nothing
-// survives from one forward to the next.  The host names the matrices that should stay resident
-// (eagle_skinny_resident_weights: the smallest ones, up to ~3/4 of the cache); those are read with the
-// default policy, every other weight with non-temporal loads so that it does not displace them.
-#define SK_MAX_RESIDENT 16
-static const void* g_sk_resident[SK_MAX_RESIDENT];
-static int g_sk_n_resident = 0;
-extern "C" int eagle_skinny_resident_weights(const void* const* weights, int n) {
-  if (n < 0 || n > SK_MAX_RESIDENT || (n > 0 && !weights)) return EAGLE_ERR_ARG;
-  for (int i = 0; i < n; ++i) g_sk_resident[i] = weights[i];
-  g_sk_n_resident = n;
-  return EAGLE_OK;
-}
-static bool sk_stream_nt(const SkinnyArgs& a, int epi) {
-  (void)epi;
-  for (int i = 0; i < g_sk_n_resident; ++i)
-    if (g_sk_resident[i] == (const void*)a.W) return false;
-  return true;
-}
+// survives from one forward to the next.  The caller marks, PER CALL (EAGLE_GEMM_KEEP_RESIDENT in `epi`), the
+// matrices that should stay resident (the host that owns the model picks the smallest ones, up to ~3/4 of the
+// cache); those are read with the default policy, every other weight with non-temporal loads so that it does not
+// displace them.  No state is kept in the library.
+#define EAGLE_GEMM_KEEP_RESIDENT 0x100
+static bool sk_stream_nt(const SkinnyArgs& a, int epi) { (void)epi; return a.nt; }
 
 template <int RT, int EPI>
 static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
@@ -664,6 +646,8 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
                                       const void* res, int64_t ldr, void* out, int64_t ldo,
                                       int M, int N, int K, int epi, hipStream_t stream) {
   if (!x0 || !W || !out) return EAGLE_ERR_ARG;
+  const bool keep_resident = (epi & EAGLE_GEMM_KEEP_RESIDENT) != 0;
+  epi &= ~EAGLE_GEMM_KEEP_RESIDENT;
   if (epi != EPI_LINEAR && epi != EPI_SILU_MUL) return EAGLE_ERR_ARG;
   if (ind0 && (!idx0 || ind_n < 1 || M > (epi == EPI_SILU_MUL ? 32 : 64))) return EAGLE_ERR_ARG;
   if (norm_eps < 0.f || (norm_eps > 0.f && x1)) return EAGLE_ERR_ARG;
@@ -687,7 +671,7 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     a.W = (const bf16_t*)W; a.W2 = (const bf16_t*)W2; a.bias = (const bf16_t*)bias;
     a.res = res ? (const bf16_t*)res + (int64_t)m0 * ldr : nullptr; a.ldr = ldr;
     a.out = (bf16_t*)out + (int64_t)m0 * ldo; a.ldo = ldo;
-    a.M = mc; a.N = N; a.K = K;
+    a.M = mc; a.N = N; a.K = K; a.nt = !keep_resident;
     int rc;
     const int var = skinny_variant();   // 3 = per-shape choice (measured); 0/1/2 force one kernel family
     const bool big = (epi == EPI_SILU_MUL) || N >= 8192;

@@ -78,11 +78,14 @@ __device__ __forceinline__ void absorb(TState& ts, OState& os, const float* tf, 
     for (int j = 7; j >= 0; --j) if (j < n && of[j] == cmo) f = j;
     os.idx = col0 + f;
   }
-  const float bt = -ts.m * L2E, bo = -os.m * L2E;
+  // everything seen so far -inf (masked / padded vocabulary columns handed in through the C ABI): the running maximum is
+  // still -inf and -m*L2E would be +inf, -inf*L2E + inf = NaN; with offset 0 the terms are exp2(-inf) = 0.  A zero
+  // probability contributes nothing to the cross term even where the other logit is -inf (0 * -inf).
+  const float bt = (ts.m == -INFINITY) ? 0.f : -ts.m * L2E, bo = (os.m == -INFINITY) ? 0.f : -os.m * L2E;
 #pragma unroll
   for (int j = 0; j < 8; ++j) if (j < n) {
     const float e = exp2f(fmaf(tf[j], L2E, bt));
-    ts.z += e; ts.a = fmaf(e, of[j], ts.a);
+    ts.z += e; ts.a = e > 0.f ? fmaf(e, of[j], ts.a) : ts.a;
     os.z += exp2f(fmaf(of[j], L2E, bo));
   }
 }
@@ -241,10 +244,10 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const bf16_t* __rest
       }
     }
     for (int v = nfull * 8 + threadIdx.x; v < V; v += CE_THREADS)
-      dr[v] = f2bf(gp * (exp2f(fmaf(bf2f(orow[v]), L2E, bo)) - exp2f(fmaf(bf2f(tr[v]), L2E, bt))));
+      dr[v] = gp == 0.f ? (bf16_t)0 : f2bf(gp * (exp2f(fmaf(bf2f(orow[v]), L2E, bo)) - exp2f(fmaf(bf2f(tr[v]), L2E, bt))));
   } else {
-    for (int v = threadIdx.x; v < V; v += CE_THREADS)
-      dr[v] = f2bf(gp * (exp2f(fmaf(bf2f(orow[v]), L2E, bo)) - exp2f(fmaf(bf2f(tr[v]), L2E, bt))));
+    for (int v = threadIdx.x; v < V; v += CE_THREADS)      // masked rows are exact zeros whatever their logits hold
+      dr[v] = gp == 0.f ? (bf16_t)0 : f2bf(gp * (exp2f(fmaf(bf2f(orow[v]), L2E, bo)) - exp2f(fmaf(bf2f(tr[v]), L2E, bt))));
   }
   if (dpred) {
     const float gv = mk * g_v / (float)D;

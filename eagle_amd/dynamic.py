@@ -39,6 +39,7 @@ class EagleDynamicDrafter:
         P = k + (S - 1) * k * k
         if not (1 <= k <= 16 and S >= 1 and 2 <= T <= 64 and T - 1 <= P and P <= 1024 and S + 1 <= 16):
             raise ValueError(f"steps={S}, topk={k}, num_draft_tokens={T}: need k <= 16, T <= 64, T-1 <= k+(S-1)k^2 <= 1024")
+        ops.topk_limit_check(lm_head_weight.shape[0], k)
         self.model, self.lm_head, self.S, self.k, self.T, self.P = model, lm_head_weight.contiguous(), S, k, T, P
         self.W = S + 1                                          # catch-up rows (padded) = longest accepted path + 1
         self.n_tree = (S - 1) * k                               # draft KV rows appended per cycle
@@ -47,7 +48,7 @@ class EagleDynamicDrafter:
         self.dev, self.D = dev, model.config.hidden_size
         self.keep_debug, self.debug = keep_debug, []
         V = lm_head_weight.shape[0]
-        self.caches = [model._cache_for(li, 1, self.cap, dev, None) for li in range(len(model.layers))]
+        self.caches = [model.new_cache(1, self.cap, dev) for _ in model.layers]      # private: forward() never touches them
         model.set_cache_residency(self.lm_head)
         i32, i64, f32 = torch.int32, torch.int64, torch.float32
         self.len_cur = torch.zeros(1, dtype=i32, device=dev)
@@ -85,7 +86,7 @@ class EagleDynamicDrafter:
 
     # ------------------------------------------------------------------ draft side
     def _head(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int):
-        logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
+        logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows, resident=self.model._keep_resident(self.lm_head))
         # top-k and the rows' log-sum-exp out of one pass over the logits (two launches, not three)
         ops.topk(logits, self.k, out_idx=self.ids[:rows], out_val=self.vals[:rows], workspace=self._ws, lse_out=self.lse[:rows])
         if self.keep_debug:

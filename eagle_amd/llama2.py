@@ -90,12 +90,37 @@ class LlamaDecoderLayer(nn.Module):
 
 
 class _LayerCache:
-    __slots__ = ("k", "v", "cap")
+    """One preallocated KV buffer.  ``forward`` hands out views of it as ``past_key_values``; each view carries a
+    stamp (cache, epoch, rows) so that a view whose rows a later call has overwritten is recognised when it comes
+    back (the reference returns fresh tensors from torch.cat, eagle/llama2.py:236-239, so its callers may keep any
+    number of branches alive; here a branch stays alive until a call restarts the same buffer from fewer rows than
+    the branch holds -- then it is stale and handing it back raises instead of attending to foreign rows)."""
+    __slots__ = ("k", "v", "cap", "epoch", "truncs")
 
     def __init__(self, B, HK, cap, hd, device):
         self.k = torch.zeros((B, HK, cap, hd), dtype=torch.bfloat16, device=device)
         self.v = torch.zeros((B, HK, cap, hd), dtype=torch.bfloat16, device=device)
         self.cap = cap
+        self.epoch = 0                    # bumped by every call that overwrites rows handed out earlier
+        self.truncs = []                  # [(epoch, first row overwritten)] of those calls, oldest first
+
+    def views(self, total: int):
+        k, v = self.k[:, :, :total], self.v[:, :, :total]
+        k._eagle_stamp = v._eagle_stamp = (self, self.epoch, total)
+        return k, v
+
+    def restart(self, past_len: int, rows_handed_out: int):
+        """A call is about to write rows [past_len, ...): views holding more than past_len rows go stale."""
+        if past_len < rows_handed_out:
+            self.epoch += 1
+            self.truncs.append((self.epoch, past_len))
+            if len(self.truncs) > 256:                      # collapse old history conservatively
+                lo = min(t for _, t in self.truncs[:128])
+                self.truncs = [(self.truncs[127][0], lo)] + self.truncs[128:]
+
+    def is_stale(self, stamp) -> bool:
+        _, epoch, rows = stamp
+        return any(e > epoch and t < rows for e, t in self.truncs)
 
 
 class Llama2Model(nn.Module):
@@ -118,8 +143,12 @@ class Llama2Model(nn.Module):
         for param in self.embed_tokens.parameters():
             param.requires_grad = False
         self.tree_mask = None
-        self._caches: List[_LayerCache] = []
+        self._caches: List[Optional[_LayerCache]] = []   # forward()'s own buffers (drafters hold private ones)
+        self._rows_out: List[int] = []                   # most rows of each buffer ever handed out as a view
         self._packed = {}
+        self._weight_epoch = 0                           # part of every derived-weight cache key
+        self._resident = None                            # (epoch, {data_ptr}) of the matrices to keep cache-resident
+        self._resident_args = None
         self._rope = None
         self._err = None
 
@@ -144,12 +173,25 @@ class Llama2Model(nn.Module):
             self._rope = ops.rope_tables(self._dims()[2], n, base=base, device=device)
         return self._rope
 
+    def _wkey(self, srcs):
+        return (self._weight_epoch,) + tuple((w.data_ptr(), w._version) for w in srcs)
+
+    def invalidate_weight_caches(self):
+        """Drop every tensor derived from the parameters (stacked q|k|v, norm-folded gate/up, stacked gate|up, the
+        training path's transposed copies, the cache-residency choice).  In-place updates through torch bump
+        ``Tensor._version`` and are noticed without this; kernels that write parameters through raw pointers
+        (EagleTrainer's fused AdamW) and state loaders call it."""
+        self._weight_epoch += 1
+        self._packed.clear()
+        self.__dict__.pop("_tcache", None)
+        self._resident = None
+
     def _packed_weights(self, li: int):
         """q|k|v stacked into one [ (H+2HK)*hd, D ] weight so the projection is one weight pass.
         Rebuilt when any source parameter changes (in-place update or reassignment)."""
         a = self.layers[li].self_attn
         srcs = (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight)
-        key = tuple((w.data_ptr(), w._version) for w in srcs)
+        key = self._wkey(srcs)
         hit = self._packed.get(li)
         if hit is None or hit[0] != key:
             hit = (key, torch.cat([w.detach() for w in srcs], dim=0).contiguous())
@@ -161,7 +203,7 @@ class Llama2Model(nn.Module):
         (W' = W * w[None, :]); rebuilt when a source parameter changes."""
         layer = self.layers[li]
         srcs = (layer.mlp.gate_proj.weight, layer.mlp.up_proj.weight, layer.post_attention_layernorm.weight)
-        key = tuple((w.data_ptr(), w._version) for w in srcs)
+        key = self._wkey(srcs)
         hit = self._packed.get(("mlp", li))
         if hit is None or hit[0] != key:
             w = srcs[2].detach()[None, :]
@@ -173,49 +215,73 @@ class Llama2Model(nn.Module):
         """gate|up stacked into one [2I, D] weight (wide-batch path); rebuilt when a source changes."""
         m = self.layers[li].mlp
         srcs = (m.gate_proj.weight, m.up_proj.weight)
-        key = tuple((w.data_ptr(), w._version) for w in srcs)
+        key = self._wkey(srcs)
         hit = self._packed.get(("gu", li))
         if hit is None or hit[0] != key:
             hit = (key, torch.cat([w.detach() for w in srcs], dim=0).contiguous())
             self._packed[("gu", li)] = hit
         return hit[1]
 
-    def set_cache_residency(self, lm_head: Optional[torch.Tensor] = None, budget_mb: Optional[float] = None):
-        """Tell the weight-stream GEMM which of this model's matrices to keep in the Infinity Cache between
-        the draft forwards of a cycle: the smallest ones up to ``budget_mb`` (default 192 MB = 3/4 of the
-        256 MB cache; EAGLE_RESIDENT_MB overrides).  Called by the drafters; speed only."""
-        if budget_mb is None:
-            budget_mb = float(os.environ.get("EAGLE_RESIDENT_MB", "192"))
-        cands = [self.fc.weight]
-        for li, layer in enumerate(self.layers):
-            cands += [self._packed_weights(li), layer.self_attn.o_proj.weight, tuple(self._folded_mlp(li)),
-                      layer.mlp.down_proj.weight]
-        if lm_head is not None:
-            cands.append(lm_head)
-        ops.set_resident_weights(ops.pick_resident_weights(cands, int(budget_mb * 1e6))[:16])
+    def set_cache_residency(self, lm_head: Optional[torch.Tensor] = None, budget_mb: float = 192.0):
+        """Choose which of this model's matrices the weight-stream GEMM keeps in the Infinity Cache between the draft
+        forwards of a cycle: the smallest ones up to ``budget_mb`` (default 192 MB = 3/4 of the 256 MB cache).  The
+        choice lives in the model (the library keeps no state) and reaches the kernel as a per-call flag
+        (EAGLE_GEMM_KEEP_RESIDENT); it is recomputed when the derived weights are rebuilt.  Speed only."""
+        self._resident_args = (lm_head, float(budget_mb))
+        self._resident = None
+
+    def _keep_resident(self, w: torch.Tensor) -> bool:
+        if self._resident_args is None:
+            return False
+        if self._resident is None or self._resident[0] != self._weight_epoch:
+            lm_head, budget_mb = self._resident_args
+            cands = [self.fc.weight]
+            for li, layer in enumerate(self.layers):
+                cands += [self._packed_weights(li), layer.self_attn.o_proj.weight, tuple(self._folded_mlp(li)),
+                          layer.mlp.down_proj.weight]
+            if lm_head is not None:
+                cands.append(lm_head)
+            picked = ops.pick_resident_weights(cands, int(budget_mb * 1e6))
+            self._resident = (self._weight_epoch, {t.data_ptr() for t in picked})
+        return w.data_ptr() in self._resident[1]
+
+    def new_cache(self, B: int, cap: int, device) -> "_LayerCache":
+        """A private KV buffer (the drafters own theirs: nothing forward() does can overwrite them)."""
+        _, HK, hd = self._dims()
+        return _LayerCache(B, HK, (cap + 255) // 256 * 256, hd, device)
 
     def _cache_for(self, li: int, B: int, need: int, device, past) -> _LayerCache:
-        H, HK, hd = self._dims()
+        """The buffer this call appends to.  A ``past`` that is a stamped view of the model's current buffer for the
+        layer continues in place (raises if a later call overwrote rows it holds); any other past (a view of an
+        older buffer, a clone, a foreign tensor) is copied into a fresh buffer, and a call without past starts a
+        fresh buffer too, so views handed out earlier keep their contents like the reference's torch.cat results."""
         while len(self._caches) <= li:
             self._caches.append(None)
+            self._rows_out.append(0)
         c = self._caches[li]
-        ours = (c is not None and past is not None and past[0].data_ptr() == c.k.data_ptr()
-                and past[1].data_ptr() == c.v.data_ptr() and past[0].stride() == c.k.stride()
-                and past[0].shape[0] == B)
-        if c is None or c.k.shape[0] != B or c.cap < need or c.k.device != device:
-            cap = max(need, getattr(self.config, "max_position_embeddings", 2048))
-            cap = (cap + 255) // 256 * 256
-            nc = _LayerCache(B, HK, cap, hd, device)
-            if past is not None:
-                pl = past[0].shape[2]
-                nc.k[:, :, :pl].copy_(past[0])
-                nc.v[:, :, :pl].copy_(past[1])
-            self._caches[li] = c = nc
-        elif past is not None and not ours:
-            pl = past[0].shape[2]
-            c.k[:, :, :pl].copy_(past[0])
-            c.v[:, :, :pl].copy_(past[1])
-        return c
+        past_len = 0 if past is None else past[0].shape[2]
+        stamp_k = getattr(past[0], "_eagle_stamp", None) if past is not None else None
+        stamp_v = getattr(past[1], "_eagle_stamp", None) if past is not None else None
+        ours = (c is not None and stamp_k is not None and stamp_k[0] is c and stamp_v is not None and stamp_v[0] is c
+                and past[0].shape[0] == B and c.k.device == device)
+        if ours:
+            if c.is_stale(stamp_k) or c.is_stale(stamp_v):
+                raise ValueError(
+                    "past_key_values is a view of the model's KV buffer whose rows a later forward() overwrote "
+                    "(a call restarted that buffer from fewer rows); clone() the tensors of a branch that must "
+                    "outlive such a call")
+            if c.cap >= need:
+                c.restart(past_len, self._rows_out[li])
+                self._rows_out[li] = min(self._rows_out[li], past_len)
+                return c
+        cap = max(need, getattr(self.config, "max_position_embeddings", 2048))
+        nc = self.new_cache(B, cap, device)
+        if past is not None:
+            nc.k[:, :, :past_len].copy_(past[0])
+            nc.v[:, :, :past_len].copy_(past[1])
+        self._caches[li] = nc
+        self._rows_out[li] = 0
+        return nc
 
     # ------------------------------------------------------------------ kernel chain
     def _attn_workspace(self, B, H, max_kv, dev):
@@ -256,12 +322,13 @@ class Llama2Model(nn.Module):
             x = _gemm_wide(ops.embed_concat(emb_w, emb_idx, hid), self.fc.weight, bias=self.fc.bias)
         else:
             x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
-                                  ind0=emb_ind, idx0_bstride=emb_bstride)
+                                  ind0=emb_ind, idx0_bstride=emb_bstride, resident=self._keep_resident(self.fc.weight))
         for li, layer in enumerate(self.layers):
             a = layer.self_attn
             cache = caches[li]
             xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
-            qkv = _gemm_wide(xin, self._packed_weights(li)) if wide_rest else ops.linear_skinny(xin, self._packed_weights(li))
+            wqkv = self._packed_weights(li)
+            qkv = _gemm_wide(xin, wqkv) if wide_rest else ops.linear_skinny(xin, wqkv, resident=self._keep_resident(wqkv))
             attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
             ws = self._attn_workspace(B, H, (past_host + q_len) if past_host is not None else max_kv, dev)
             for r0 in range(0, q_len, 16):
@@ -269,7 +336,8 @@ class Llama2Model(nn.Module):
                 bound = (past_host + r0 + mq) if past_host is not None else max_kv
                 ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, past_off0 + r0, tmask, pad, attn, ws,
                                    self._err, B, mq, H, HK, hd, bound, True, q_len, r0, pos_off, pos_stride)
-            x = _gemm_wide(attn, a.o_proj.weight, res=x) if wide_rest else ops.linear_skinny(attn, a.o_proj.weight, res=x)
+            x = _gemm_wide(attn, a.o_proj.weight, res=x) if wide_rest else \
+                ops.linear_skinny(attn, a.o_proj.weight, res=x, resident=self._keep_resident(a.o_proj.weight))
             # post_attention_layernorm fused into the gate/up projection: the norm weight is folded
             # into the weight columns, the row scale rsqrt(mean(x^2)+eps) is computed in-kernel
             if M > 64 and x.shape[1] % 64 == 0:
@@ -280,11 +348,13 @@ class Llama2Model(nn.Module):
                 act = ops.silu_mul(_gemm_wide(n, wgu))
             else:
                 wg, wu = self._folded_mlp(li)
-                act = ops.linear_skinny(x, wg, W2=wu, norm_eps=layer.post_attention_layernorm.variance_epsilon)
+                act = ops.linear_skinny(x, wg, W2=wu, norm_eps=layer.post_attention_layernorm.variance_epsilon,
+                                        resident=self._keep_resident(wg))
             if wide_rest and act.shape[1] % 64 == 0:
                 x = _gemm_wide(act, layer.mlp.down_proj.weight, res=x)
             else:
-                x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x)
+                x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x,
+                                      resident=self._keep_resident(layer.mlp.down_proj.weight))
         return x
 
     # ------------------------------------------------------------------ forward
@@ -358,7 +428,9 @@ class Llama2Model(nn.Module):
         x = self._forward_rows(ids, hs, None, M, B, q_len, pos, past_dev, None, tmask, pad, caches, past_len)
         next_cache = None
         if use_cache:
-            next_cache = tuple((c.k[:, :, :total], c.v[:, :, :total]) for c in caches)
+            next_cache = tuple(c.views(total) for c in caches)
+            for li in range(len(caches)):
+                self._rows_out[li] = max(self._rows_out[li], total)
         out = x.view(B, q_len, D)
         if use_cache:
             return out, next_cache

@@ -15,6 +15,7 @@ from ._hip import call, ptr, query, stream
 
 BF16 = torch.bfloat16
 EPI_LINEAR, EPI_SILU_MUL = 0, 1
+KEEP_RESIDENT = 0x100   # EAGLE_GEMM_KEEP_RESIDENT
 
 
 def _chk(t: torch.Tensor, name: str, dtype=BF16):
@@ -29,10 +30,11 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
                   idx0: Optional[torch.Tensor] = None, x1: Optional[torch.Tensor] = None,
                   idx1: Optional[torch.Tensor] = None, M: Optional[int] = None,
                   out: Optional[torch.Tensor] = None, ind0: Optional[torch.Tensor] = None,
-                  idx0_bstride: int = 0, norm_eps: float = 0.0) -> torch.Tensor:
+                  idx0_bstride: int = 0, norm_eps: float = 0.0, resident: bool = False) -> torch.Tensor:
     """out[M,N] = epi(cat(x[idx0], x1[idx1]) @ W^T).  x [*, K0] row-major; W [N, K].
     ind0: double indirection for x rows (see include/eagle_hip.h); norm_eps > 0 fuses the RMSNorm
-    row scale (W must then carry the norm weight folded into its columns)."""
+    row scale (W must then carry the norm weight folded into its columns).  resident: keep W in the Infinity Cache
+    (default cache policy) instead of streaming it with non-temporal loads."""
     _chk(x, "x"), _chk(W, "W")
     N, K = W.shape
     K0 = x.shape[-1]
@@ -51,21 +53,13 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
             raise TypeError("row index arrays must be contiguous int64")
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=x.device)
-    epi = EPI_SILU_MUL if W2 is not None else EPI_LINEAR
+    epi = (EPI_SILU_MUL if W2 is not None else EPI_LINEAR) | (KEEP_RESIDENT if resident else 0)
     call("eagle_gemm_skinny_bf16", ptr(x), ptr(idx0), x.stride(0) if x.dim() > 1 else K0, K0,
          ptr(ind0), (ind0.numel() if ind0 is not None else 0), idx0_bstride, float(norm_eps),
          ptr(x1), ptr(idx1), (x1.stride(0) if x1 is not None else 0),
          ptr(W), ptr(W2), ptr(bias), ptr(res), (res.stride(0) if res is not None else 0),
          ptr(out), out.stride(0), M, N, K, epi, stream())
     return out
-
-
-def set_resident_weights(weights) -> None:
-    """Name the weight matrices eagle_gemm_skinny_bf16 should keep cache-resident (see include/eagle_hip.h)."""
-    import ctypes
-    ws = list(weights)
-    arr = (ctypes.c_void_p * max(1, len(ws)))(*[w.data_ptr() for w in ws])
-    call("eagle_skinny_resident_weights", ctypes.cast(arr, ctypes.c_void_p), len(ws))
 
 
 def pick_resident_weights(weights, budget_bytes: int):
@@ -152,6 +146,10 @@ def rmsnorm_bwd(dy, x, w, rstd, res=None, dw: Optional[torch.Tensor] = None, acc
 
 def embed_concat(emb: torch.Tensor, ids: torch.Tensor, hidden: torch.Tensor) -> torch.Tensor:
     _chk(emb, "emb"), _chk(hidden, "hidden")
+    if ids.dtype != torch.int64 or not ids.is_contiguous() or not ids.is_cuda:
+        raise TypeError("embed_concat: ids must be a contiguous int64 device tensor")
+    if hidden.dim() != 2 or hidden.stride(1) != 1 or ids.numel() != hidden.shape[0]:
+        raise ValueError("embed_concat: hidden [N, D] with contiguous rows, ids [N]")
     N, D = hidden.shape
     out = torch.empty((N, 2 * D), dtype=BF16, device=hidden.device)
     call("eagle_embed_concat_bf16", ptr(emb), ptr(ids), ptr(hidden), hidden.stride(0), ptr(out), N, D, emb.shape[0], stream())
@@ -312,6 +310,7 @@ def topk(logits: torch.Tensor, k: int, want_values: bool = True,
     if not logits.is_cuda:
         raise _hip.HipKernelError("topk: device tensor required")
     total_rows, V = logits.shape
+    topk_limit_check(V, k)
     if block_index is None:
         rows = total_rows
     elif rows is None or total_rows % rows:
@@ -340,6 +339,49 @@ def topk(logits: torch.Tensor, k: int, want_values: bool = True,
 
 def first_argmax(logits: torch.Tensor) -> torch.Tensor:
     return topk(logits, 1, want_values=False)[1][:, 0]
+
+
+def tree_layout(paths, topk: int, expand_all: bool):
+    """Host-side validation + sizes of a static tree (eagle_tree_layout).  Returns (paths int32 [n, width] CPU tensor,
+    meta dict).  Raises ValueError on an invalid tree."""
+    import ctypes
+    paths = [list(p) for p in paths]
+    if not paths or any(len(p) < 1 for p in paths):
+        raise ValueError("tree paths must be non-empty")
+    width = max(len(p) for p in paths)
+    arr = torch.full((len(paths), width), -1, dtype=torch.int32)
+    for i, p in enumerate(paths):
+        arr[i, :len(p)] = torch.tensor(p, dtype=torch.int32)
+    meta = (ctypes.c_int32 * 32)()
+    rc = _hip.lib().eagle_tree_layout(arr.data_ptr(), len(paths), width, int(topk), int(expand_all), ctypes.cast(meta, ctypes.c_void_p))
+    if rc:
+        raise ValueError(f"invalid draft tree (duplicate path, path without its parent, choice outside top-{topk}, "
+                         f"more than 63 paths / depth 15, or a depth with nothing to expand): {_hip._ERR.get(rc, rc)}")
+    m = list(meta)
+    return arr, {"n_nodes": m[0], "max_depth": m[1], "n_steps": m[2], "n_fwd": m[3], "n_flat_rows": m[4], "P": m[5],
+                 "W": m[6], "mask_bytes": m[7], "step_n": m[8:8 + m[2]]}
+
+
+def tree_build(paths, topk: int, expand_all: bool, device):
+    """Every a19 / a21 buffer of a static tree, built on the device (eagle_tree_build).  Returns (meta, dict of tensors)."""
+    arr, meta = tree_layout(paths, topk, expand_all)
+    n, P_, W, nf = meta["n_nodes"], meta["P"], meta["W"], meta["n_fwd"]
+    i64, i32, u8 = torch.int64, torch.int32, torch.uint8
+    o = {"tree_indices": torch.empty(n, dtype=i64, device=device), "tree_position_ids": torch.empty(n, dtype=i64, device=device),
+         "tree_attn_mask": torch.empty((n, n), dtype=u8, device=device), "retrieve_indices": torch.empty((P_, W), dtype=i64, device=device),
+         "parent": torch.empty(n, dtype=i32, device=device), "flat_row": torch.empty(n, dtype=i32, device=device),
+         "step_tree_indices": torch.empty(max(nf, 1), dtype=i64, device=device), "step_parent_row": torch.empty(max(nf, 1), dtype=i64, device=device),
+         "step_repeat_nums": torch.empty(max(nf, 1), dtype=i32, device=device),
+         "step_attn_mask": torch.empty(max(meta["mask_bytes"], 1), dtype=u8, device=device)}
+    err = torch.zeros(1, dtype=i32, device=device)
+    dpaths = arr.to(device)
+    call("eagle_tree_build", ptr(dpaths), arr.shape[0], arr.shape[1], int(topk), int(expand_all), ptr(o["tree_indices"]),
+         ptr(o["tree_position_ids"]), ptr(o["tree_attn_mask"]), ptr(o["retrieve_indices"]), ptr(o["parent"]), ptr(o["flat_row"]),
+         ptr(o["step_tree_indices"]), ptr(o["step_parent_row"]), ptr(o["step_repeat_nums"]), ptr(o["step_attn_mask"]), ptr(err),
+         stream())
+    if int(err.item()):
+        raise _hip.HipKernelError("eagle_tree_build rejected a tree eagle_tree_layout accepted")
+    return meta, o
 
 
 def tree_gather_ids(flat_ids: torch.Tensor, tree_idx: torch.Tensor, B: int = 1, out=None,
@@ -412,9 +454,24 @@ def ce_stat_bytes() -> int:
     return query("eagle_ce_stat_bytes")
 
 
+def _rows_d(x, name, N):
+    """predict / target reach the loss kernels as bare pointers with row stride D."""
+    _chk(x, name)
+    if x.dim() != 2 or x.shape[0] != N or not x.is_contiguous():
+        raise ValueError(f"{name}: contiguous [N, D] rows required (got shape {tuple(x.shape)}, strides {x.stride()})")
+
+
+def topk_limit_check(V: int, k: int) -> None:
+    """eagle_topk_vocab merges ceil(V/1024)*k stage-1 candidates per row in one 256-thread workgroup (<= 2048)."""
+    if not 1 <= k <= 16 or ((V + 1023) // 1024) * k > 2048:
+        raise ValueError(f"top-{k} over a {V}-entry vocabulary exceeds the kernel's limits (k <= 16, ceil(V/1024)*k <= 2048)")
+
+
 def ce_partial(t_logits, o_logits, v0: int = 0, predict=None, target=None):
     _chk(t_logits, "t_logits"), _chk(o_logits, "o_logits")
     N, V = t_logits.shape
+    if predict is not None:
+        _rows_d(predict, "predict", N), _rows_d(target, "target", N)
     if t_logits.stride() != o_logits.stride() or t_logits.stride(1) != 1:
         raise ValueError("logit tensors must share one row-major layout")
     D = predict.shape[-1] if predict is not None else 0
@@ -441,6 +498,8 @@ def ce_combine(stats: torch.Tensor, mask: Optional[torch.Tensor]):
 def ce_smoothl1_bwd(t_logits, o_logits, lse_t, lse_o, mask, g_p: float, g_v: float, predict=None, target=None,
                     in_place: bool = False):
     N, V = t_logits.shape
+    if predict is not None:
+        _rows_d(predict, "predict", N), _rows_d(target, "target", N)
     dlog = o_logits if in_place else torch.empty_like(o_logits)
     dpred = torch.empty_like(predict) if predict is not None else None
     D = predict.shape[-1] if predict is not None else 0

@@ -48,8 +48,9 @@ class EagleDrafter:
         dev = lm_head_weight.device
         if lm_head_weight.dtype != BF16 or not lm_head_weight.is_cuda:
             raise TypeError("lm_head weight must be a bf16 device tensor")
+        ops.topk_limit_check(lm_head_weight.shape[0], topk)
         self.model, self.lm_head, self.B, self.k = model, lm_head_weight.contiguous(), batch, topk
-        self.tb = TreeBuffers(tree, topk=topk, expand=expand, device=dev)
+        self.tb = TreeBuffers.build_on_device(tree, topk=topk, expand=expand, device=dev)   # eagle_tree_build (C ABI)
         self.W = self.tb.max_depth + 1                       # catch-up rows per request (padded)
         if self.W > 16 or max(len(s.nodes) for s in self.tb.steps) > 16:
             raise ValueError("the tree attention kernel takes at most 16 query rows per request and step")
@@ -62,7 +63,7 @@ class EagleDrafter:
         # that knows a tighter bound for the coming cycles may lower it (must stay >= the true length)
         self.kv_bound = self.cap
         B, V = batch, lm_head_weight.shape[0]
-        self.caches = [model._cache_for(li, B, self.cap, dev, None) for li in range(len(model.layers))]
+        self.caches = [model.new_cache(B, self.cap, dev) for _ in model.layers]      # private: forward() never touches them
         model.set_cache_residency(self.lm_head)
         # draft KV-cache lengths: len_cur = rows before the catch-up forward, len_nxt = after it
         self.len_cur = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -104,7 +105,7 @@ class EagleDrafter:
             # passes over the weights once per 32 rows: 304 vs 520 us at 32 rows of the 151936-row head)
             logits = ops.gemm_nt(x if idx is None else x.index_select(0, idx[:rows]), self.lm_head)
         else:
-            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
+            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows, resident=self.model._keep_resident(self.lm_head))
         if self.B == 1:
             ops.topk(logits, self.k, out_idx=self.flat_ids[0, row0:row0 + n], out_val=self.flat_vals[0, row0:row0 + n],
                      workspace=self._ws)

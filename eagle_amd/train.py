@@ -449,12 +449,16 @@ class EagleTrainer:
             hs = mb["hidden_states"]
             B, L, D = hs.shape
             cos, sin = model._rope_tables(max(L, model.config.max_position_embeddings), dev)
-            predict, saved = draft_fwd(W, model.embed_tokens.weight.detach(), mb["input_ids"].reshape(-1).contiguous(),
-                                       hs.reshape(B * L, D), B, L, H, hd, cos, sin)
+            if hs.dtype != BF16 or mb["target"].dtype != BF16:
+                raise TypeError("EagleTrainer.step: hidden_states and target must be bf16")
+            ids = mb["input_ids"].reshape(-1).to(torch.int64).contiguous()
+            tgt = mb["target"].reshape(B * L, D).contiguous()
+            predict, saved = draft_fwd(W, model.embed_tokens.weight.detach(), ids, hs.reshape(B * L, D).contiguous(), B, L, H, hd,
+                                       cos, sin)
             if self.sharded_loss is not None:
-                sums, dpred = self.sharded_loss.fwd_bwd(predict, mb["target"].reshape(B * L, D), masks[i], self.v_w, self.p_w, scale)
+                sums, dpred = self.sharded_loss.fwd_bwd(predict, tgt, masks[i], self.v_w, self.p_w, scale)
             else:
-                sums, dpred = loss_fwd_bwd(predict, mb["target"].reshape(B * L, D), self.lm_head, self.lm_head_t, masks[i],
+                sums, dpred = loss_fwd_bwd(predict, tgt, self.lm_head, self.lm_head_t, masks[i],
                                            self.v_w, self.p_w, scale)
             self._sums += sums
             sink = self._grad_sink(accumulate=i > 0)
@@ -533,6 +537,9 @@ class EagleTrainer:
         ops.adamw_(self.flat, self.grad, self.m, self.v, lr, self.betas[0], self.betas[1], self.eps, self.wd,
                    self.step_count, grad_scale=coef, clip_value=clip_value)
         self._pversion += 1
+        # the kernel above wrote the parameters through raw pointers (no Tensor._version bump): drop what the
+        # model derived from the old values (stacked / norm-folded decode weights, transposed copies)
+        self.model.invalidate_weight_caches()
         # accelerate's scheduler steps once per process per call (accelerate/scheduler.py:73-76)
         self.sched_step += self.world if self.mode == "dp" else 1
 

@@ -142,6 +142,44 @@ class TreeBuffers:
         self.tree_position_ids = torch.tensor(dep, dtype=torch.int64, device=device)
         self.retrieve_indices = torch.tensor(rows, dtype=torch.int64, device=device)
 
+    @classmethod
+    def build_on_device(cls, paths: Sequence[Sequence[int]] = mc_sim_7b_63, topk: int = TOPK, expand: str = "wchild",
+                        device="cuda") -> "TreeBuffers":
+        """The same buffers through the C ABI (eagle_tree_layout + eagle_tree_build): the index logic runs in the
+        library (host analysis for the sizes, one kernel for the contents), which is what a non-Python host binds.
+        The drafters use this path; ``TreeBuffers(...)`` above is the host-only equivalent (CPU tests, tooling)."""
+        from . import ops
+        if expand not in ("wchild", "all"):
+            raise ValueError(f"expand must be 'wchild' or 'all', got {expand!r}")
+        meta, o = ops.tree_build(paths, topk, expand == "all", device)
+        self = cls.__new__(cls)
+        n = meta["n_nodes"]
+        self.topk, self.n_nodes, self.expand = topk, n, expand
+        self.parent = o["parent"].cpu().tolist()
+        self.depth = o["tree_position_ids"].cpu().tolist()
+        ti = o["tree_indices"].cpu().tolist()
+        self.choice = [-1] + [(ti[i] - 1) % topk for i in range(1, n)]
+        self.max_depth = meta["max_depth"]
+        self.flat_row = o["flat_row"].cpu().tolist()
+        self.n_flat_rows = meta["n_flat_rows"]
+        fwd = [i for i in range(1, n) if self.flat_row[i] > 0]
+        reps = o["step_repeat_nums"].cpu().tolist()
+        self.steps = []
+        first, moff, cols, row_base = 0, 0, 0, 1
+        for nd in meta["step_n"]:
+            cols += nd
+            m = o["step_attn_mask"][moff:moff + nd * cols].view(nd, cols)
+            self.steps.append(DraftStep(
+                nodes=fwd[first:first + nd], tree_indices=o["step_tree_indices"][first:first + nd],
+                parent_row=o["step_parent_row"][first:first + nd], repeat_nums=[r for r in reps[first:first + nd] if r > 0],
+                position_ids=torch.zeros(nd, dtype=torch.int64, device=device), attn_mask=m.to(torch.float32)[None, None],
+                attn_mask_u8=m, row_base=row_base))
+            first, moff, row_base = first + nd, moff + nd * cols, row_base + nd
+        self.tree_attn_mask = o["tree_attn_mask"].to(torch.float32)[None, None]
+        self.tree_indices, self.tree_position_ids = o["tree_indices"], o["tree_position_ids"]
+        self.retrieve_indices = o["retrieve_indices"]
+        return self
+
     # dict view with the upstream key names (what ``model.tree_buffer[...]`` users index)
     def as_dict(self) -> dict:
         return {
@@ -154,4 +192,8 @@ class TreeBuffers:
 
 def generate_tree_buffers(tree_choices=mc_sim_7b_63, device="cuda", topk: int = TOPK,
                           expand: str = "wchild") -> TreeBuffers:
+    """The name eagle/llama2.py:455 calls.  Device buffers are built by the library (C ABI); a CPU ``device`` gets the
+    host-only construction (there is no CPU compute path, but index buffers are plain integers)."""
+    if torch.device(device).type == "cuda":
+        return TreeBuffers.build_on_device(tree_choices, topk=topk, expand=expand, device=device)
     return TreeBuffers(tree_choices, topk=topk, expand=expand, device=device)

@@ -24,6 +24,10 @@ typedef struct ihipStream_t* eagle_stream_t; /* == hipStream_t */
 
 #define EAGLE_EPI_LINEAR 0
 #define EAGLE_EPI_SILU_MUL 1
+/* OR-ed into `epi` of eagle_gemm_skinny_bf16: read W (and W2) with the default cache policy so that the matrix can stay
+ * in the 256 MB Infinity Cache from one draft forward to the next; without it weights stream with non-temporal loads
+ * and displace nothing.  A per-call hint (the library keeps no state); it only changes speed, never results. */
+#define EAGLE_GEMM_KEEP_RESIDENT 0x100
 
 /* out[M,N] = epilogue(x[M,K] . W[N,K]^T), weight-streaming kernel for M <= 64 rows per weight
  * pass (larger M loops).  x row m = cat(x0[idx0 ? idx0[m] : m][0:K0], x1[idx1 ? idx1[m] : m][0:K-K0])
@@ -43,14 +47,6 @@ int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int
                            const void* W, const void* W2, const void* bias,
                            const void* res, int64_t ldr, void* out, int64_t ldo,
                            int M, int N, int K, int epi, eagle_stream_t stream);
-
-/* Cache-policy hint for eagle_gemm_skinny_bf16 (no counterpart in the reference: eager nn.Linear has no
- * such knob): the listed weight matrices (device pointers as later passed in `W`, n <= 16; n = 0 clears)
- * are streamed with the default cache policy so that they can stay in the 256 MB Infinity Cache from
- * one draft forward to the next; every other weight is read with non-temporal loads.  Process-wide,
- * set once by the host that owns the model (eagle_amd.speculative picks the smallest matrices up to
- * a byte budget); a stale or missing list only changes speed, never results. */
-int eagle_skinny_resident_weights(const void* const* weights, int n);
 
 /* C[M,N] = epilogue(A[M,K] . B[N,K]^T): LDS-tiled MFMA GEMM (128x128x64 tiles, LDS-DMA staging)
  * for training-size M.  (+bias[N]) (+res[M,N] bf16); C is bf16 (out_f32 = 0) or fp32 (1);
@@ -166,6 +162,29 @@ int eagle_topk_vocab_noalloc(const void* logits, int64_t ld, int dtype, int rows
 
 /* Static-tree kernels (Llama2Model.init_tree / tree_mask hooks,
  * eagle/llama2.py:453-458 -- the algorithm itself is the upstream EAGLE-1 one). */
+/* generate_tree_buffers, the name Llama2Model.init_tree calls without defining it (eagle/llama2.py:453-455; the tree
+ * itself, mc_sim_7b_63, is the 25-path list of SURVEY.md a18).  paths [n_paths, width] int32, -1 padded, any order;
+ * nodes = paths sorted by (length, path), node 0 = root; n_paths + 1 <= 64, width <= 15, every choice < topk.
+ * expand_all = 0: only nodes that have children are run through the draft head (upstream), 1: every node.
+ * eagle_tree_layout (paths in HOST memory; launches nothing) validates the tree -- duplicate path, missing parent,
+ * choice >= topk, empty depth: EAGLE_ERR_SHAPE -- and returns the sizes in meta[32]: [0] n_nodes, [1] max_depth,
+ * [2] n_steps, [3] n_fwd, [4] n_flat_rows = 1 + n_fwd, [5] P, [6] W = max_depth + 1, [7] bytes of step_attn_mask,
+ * [8 + d] nodes of draft step d.
+ * eagle_tree_build (paths in DEVICE memory) fills, on the device:
+ *   verify side (a21): tree_indices [n] (into cat(root_token, flat_topk): 1 + topk*flat_row[parent] + choice),
+ *     tree_position_ids [n] (depth), tree_attn_mask [n,n] bytes (self | root | ancestors), retrieve_indices [P,W]
+ *     (root->leaf node ids, -1 padded, rows sorted), parent [n], flat_row [n] (-1: node not forwarded);
+ *   draft side (a19), the steps packed back to back in step order: step_tree_indices [n_fwd] (choice + topk*rank of the
+ *     parent in the previous step), step_parent_row [n_fwd], step_repeat_nums [n_fwd] (per step: run lengths of equal
+ *     parents, zero padded to the step's node count), step_attn_mask (step d: [n_d, sum_{e<=d} n_e] bytes, 1 on self
+ *     and forwarded ancestors).  All nodes of draft step d sit at position stable_len + d (position offsets are zero).
+ * A tree the device analysis rejects sets *err_flag = 1 (cannot happen after a successful eagle_tree_layout). */
+int eagle_tree_layout(const int32_t* paths_host, int n_paths, int width, int topk, int expand_all, int32_t* meta);
+int eagle_tree_build(const int32_t* paths, int n_paths, int width, int topk, int expand_all,
+                     int64_t* tree_indices, int64_t* tree_position_ids, uint8_t* tree_attn_mask,
+                     int64_t* retrieve_indices, int32_t* parent, int32_t* flat_row,
+                     int64_t* step_tree_indices, int64_t* step_parent_row, int32_t* step_repeat_nums,
+                     uint8_t* step_attn_mask, int* err_flag, eagle_stream_t stream);
 /* out_ids[b][j] = flat_ids[b][tree_idx[j]]: draft tokens of one expansion step. */
 int eagle_tree_gather_ids(const int64_t* flat_ids, int64_t flat_batch_stride, const int64_t* tree_idx,
                           int n, int64_t* out_ids, int B, eagle_stream_t stream);
@@ -296,6 +315,15 @@ int eagle_add_f32_bf16(const float* a, const void* b, void* out, int64_t n, eagl
  * last row 0; ids_out = ids shifted left with trailing 0. */
 int eagle_make_eagle_input_bf16(const void* hidden, const void* noise, const int64_t* ids, void* hidden_out,
                                 void* target, int64_t* ids_out, int B, int L, int D, eagle_stream_t stream);
+
+/* ---- diagnostics (no counterpart in the reference): kernel-family overrides for A/B measurements and for the tests
+ * that run every selectable path; process-wide, not for production hosts. ---- */
+/* eagle_gemm_nt_bf16: 0 = always the 128x128 kernel, 1 = the 256x256 kernel wherever legal, 2 = by shape (default). */
+void eagle_debug_set_gemm8(int mode);
+/* eagle_gemm_skinny_bf16 at <= 16 rows: 0 = tile kernel, 1 = streaming kernel, 2 = register-resident-x kernel where
+ * K = 4096 (streaming otherwise), 3 = by shape (default); blocks_per_cu / min_rows > 0 override the streaming
+ * kernel's grid sizing. */
+void eagle_debug_set_skinny_variant(int variant, int blocks_per_cu, int min_rows);
 
 #ifdef __cplusplus
 }

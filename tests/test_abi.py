@@ -31,6 +31,32 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_hip.SIGNATURES) == names
 
 
+def test_export_set_equals_the_header():
+    """Nothing is exported that include/eagle_hip.h does not declare (and vice versa)."""
+    import subprocess
+    from eagle_amd import _hip
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in "TW"
+                       and ln.split()[-1].startswith("eagle_")})
+    assert exported == _declared()
+
+
+def test_tree_layout_host_call():
+    """eagle_tree_layout runs on the host (no launch): sizes of the 25-path tree and rejection of invalid trees."""
+    from eagle_amd import ops
+    from eagle_amd.tree import mc_sim_7b_63
+
+    _, meta = ops.tree_layout(mc_sim_7b_63, 10, False)
+    assert meta == {"n_nodes": 26, "max_depth": 5, "n_steps": 4, "n_fwd": 10, "n_flat_rows": 11, "P": 15, "W": 6,
+                    "mask_bytes": 4 * 4 + 4 * 8 + 1 * 9 + 1 * 10, "step_n": [4, 4, 1, 1]}
+    _, meta = ops.tree_layout(mc_sim_7b_63, 10, True)
+    assert meta["step_n"] == [4, 8, 8, 3, 2] and meta["n_fwd"] == 25 and meta["n_steps"] == 5
+    for bad in ([[0], [1, 0]], [[0], [10]], [[0], [0]], [[0, 0]], [[i % 10, i // 10] for i in range(70)]):
+        with pytest.raises(ValueError):
+            ops.tree_layout(bad, 10, False)
+
+
 def test_header_cites_reference_lines():
     text = open(os.path.join(ROOT, "include", "eagle_hip.h")).read()
     for cite in ("eagle/llama2.py:515", "eagle/llama2.py:330-335", "eagle/llama2.py:226-273", "eagle/train.py:108-123"):

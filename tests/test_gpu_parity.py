@@ -22,7 +22,13 @@ def dev():
     return torch.device("cuda:0")
 
 
+MARGINS = {}     # what -> worst observed (max abs err, max err / tolerance); written out by test_zz_report_close_margins
+
+
 def close(a, b, rtol=1e-2, atol=None, what=""):
+    """|a - b| <= atol + rtol*|b| with atol = 2 % of the mean magnitude + one bf16 ulp (2^-8) at the largest magnitude
+    (the residual stream is rounded to bf16 at its own scale before cancellation); up to 0.1 % of the elements may
+    exceed it by less than 3x (one-ulp flips).  The worst observed error of every call is recorded per ``what``."""
     a, b = a.float().cpu(), b.float().cpu()
     scale = float(b.abs().mean()) + 1e-12
     # default absolute floor: 2% of the mean magnitude plus one bf16 ulp (2^-8) at the largest
@@ -31,6 +37,9 @@ def close(a, b, rtol=1e-2, atol=None, what=""):
     err = (a - b).abs()
     tol = atol + rtol * b.abs()
     bad = int((err > tol).sum())
+    prev = MARGINS.get(what, (0.0, 0.0, 0.0))
+    MARGINS[what] = (max(prev[0], float(err.max())), max(prev[1], float((err / tol).max())),
+                     max(prev[2], float(((a - b).norm() / (b.norm() + 1e-30)))))
     # bf16 outputs can legitimately flip one ulp (2^-8 relative): allow a few stragglers at 2x
     assert bad <= 1e-3 * a.numel() and float((err / (tol)).max()) < 3.0, \
         f"{what}: {bad}/{a.numel()} outside tol, max err {float(err.max()):.4g} (scale {scale:.4g})"
@@ -481,7 +490,7 @@ def test_sharded_ce_partials_combine_exactly_like_unsharded():
 
 # ------------------------------------------------------------------ draft / verify cycle
 @pytest.mark.parametrize("expand", ["wchild", "all"])
-def test_drafter_cycle_matches_oracle_loop(expand):
+def test_drafter_cycle_index_logic_matches_oracle_loop_on_hip_logits(expand):
     """The device-resident cycle (padded catch-up, device lengths, device top-k / gathers) against
     the oracle's expansion loop + acceptance + compaction.  Both sides get their logits from the
     same HIP kernels (the oracle loop calls the public Llama2Model.forward and the lm_head GEMM), so
@@ -595,7 +604,6 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
     import ctypes
     from eagle_amd import _hip, ops
     setm = _hip.lib().eagle_debug_set_gemm8
-    setm.argtypes, setm.restype = [ctypes.c_int], None
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(BF)
     Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF)
@@ -836,3 +844,19 @@ def test_topk_full_vocab_properties():
         assert torch.equal(i[r].cpu(), ot.stable_topk(x[r].cpu(), 10)[1])
     am = ops.first_argmax(x)
     assert torch.equal(am, i[:, 0])
+
+
+def test_zz_report_close_margins():
+    """Writes the worst error every `close()` call of this file saw (absolute, relative to its tolerance, relative L2)
+    so that the margin under the stated bf16 rtol 1e-2 is visible (gpurun_out/close_margins.json; copied to profiles/)."""
+    import json
+    assert MARGINS, "runs after the tests above"
+    out = {k: {"max_abs_err": v[0], "max_err_over_tol": v[1], "rel_l2": v[2]} for k, v in sorted(MARGINS.items())}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "close_margins.json"), "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError:
+        pass
+    assert max(v[1] for v in MARGINS.values()) < 3.0

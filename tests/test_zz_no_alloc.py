@@ -17,10 +17,12 @@ def _both(logits, k):
     i1, v1 = i0.clone(), v0.clone()
     _hip.call("eagle_topk_vocab", _hip.ptr(logits), logits.stride(0), dt, rows, V, k, _hip.ptr(i0), _hip.ptr(v0), _hip.ptr(ws),
               None, rows, _hip.stream())
+    import gc
+    gc.collect()                                     # garbage of earlier tests must not be freed between the two readings
     before = torch.cuda.memory_allocated()
     _hip.call("eagle_topk_vocab_noalloc", _hip.ptr(logits), logits.stride(0), dt, rows, V, k, _hip.ptr(i1), _hip.ptr(v1),
               None, rows, _hip.stream())
-    assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.memory_allocated() <= before     # nothing was allocated through torch either
     torch.cuda.synchronize()
     return i0, v0, i1, v1
 

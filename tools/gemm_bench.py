@@ -10,17 +10,14 @@ shapes = [(2048, 4096, 8192, 'fc'), (2048, 12288, 4096, 'qkv'), (2048, 4096, 409
 import ctypes
 from eagle_amd import _hip
 setm = _hip.lib().eagle_debug_set_gemm8
-setm.argtypes, setm.restype = [ctypes.c_int], None
-setpp = _hip.lib().eagle_debug_set_gemm8_pingpong
-setpp.argtypes, setpp.restype = [ctypes.c_int], None
 shapes = [(MT if M == 2048 else M, N, MT if K == 2048 else K, n) for M, N, K, n in shapes[:8]]
 shapes += [(4096, 4096, MT, 'wgrad o'), (12288, 4096, MT, 'wgrad qkv'), (4096, 8192, MT, 'wgrad fc'), (24576, 4096, MT, 'wgrad gate|up'), (4096, 12288, MT, 'wgrad down')]
 for M, N, K, name in shapes:
     A = torch.randn(M, K, device=dev).to(torch.bfloat16); B = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
     C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     it = 10
-    for mode, pp in ((0, 0), (1, 0), (1, 1)):
-        setm(mode); setpp(pp)
+    for mode, pp in ((0, 0), (1, 1)):
+        setm(mode)
         for _ in range(3): ops.gemm_nt(A, B, out=C)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

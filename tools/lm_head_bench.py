@@ -5,7 +5,6 @@ from eagle_amd import ops, _hip
 from eagle_amd.llama2 import _gemm_wide
 dev = torch.device("cuda:0")
 setm = _hip.lib().eagle_debug_set_gemm8
-setm.argtypes, setm.restype = [ctypes.c_int], None
 scrub = torch.empty(1 << 27, dtype=torch.float32, device=dev)
 
 def timeit(fn, it=6):

@@ -14,7 +14,6 @@ def t(fn, n=20):
 import ctypes
 from eagle_amd import _hip
 setv = _hip.lib().eagle_debug_set_skinny_variant
-setv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]; setv.restype = None
 shapes = [(4096, 4096), (12288, 4096), (32000, 4096), (151936, 4096)]
 for M in (1, 8):
     for N, K in shapes:
