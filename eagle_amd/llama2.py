@@ -379,8 +379,7 @@ class Llama2Model(nn.Module):
             return draft_forward_train(self, hidden_states, input_ids, attention_mask, position_ids)
         if output_attentions:
             raise NotImplementedError("attention weights are never materialised by the fused kernel")
-        if not hidden_states.is_cuda:
-            raise ops._hip.HipKernelError("Llama2Model.forward needs device tensors: eagle_amd has no CPU path")
+        ops.require_device(hidden_states, "Llama2Model.forward")
         if hidden_states.dtype != torch.bfloat16:
             raise TypeError("eagle_amd computes in bf16 only (cast the model and inputs to torch.bfloat16)")
         B, q_len, D = hidden_states.shape

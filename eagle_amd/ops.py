@@ -25,6 +25,12 @@ def _chk(t: torch.Tensor, name: str, dtype=BF16):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
 
 
+def require_device(t: torch.Tensor, what: str) -> None:
+    """There is no CPU path: every entry into the kernels goes through this check."""
+    if not t.is_cuda:
+        raise _hip.HipKernelError(f"{what} needs device tensors: eagle_amd has no CPU path")
+
+
 def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                   res: Optional[torch.Tensor] = None, W2: Optional[torch.Tensor] = None,
                   idx0: Optional[torch.Tensor] = None, x1: Optional[torch.Tensor] = None,

@@ -257,8 +257,7 @@ def draft_forward_train(model, hidden_states, input_ids, attention_mask=None, po
     """Llama2Model.forward for ``model.training`` (eagle/train.py:105): [B,L,D] -> [B,L,D] with grad."""
     if attention_mask is not None:
         raise NotImplementedError("the training forward is causal-only: eagle/train.py:105 passes no attention_mask")
-    if not hidden_states.is_cuda:
-        raise ops._hip.HipKernelError("Llama2Model.forward needs device tensors: eagle_amd has no CPU path")
+    ops.require_device(hidden_states, "Llama2Model.forward")
     if hidden_states.dtype != BF16:
         raise TypeError("eagle_amd computes in bf16 only (cast the model and inputs to torch.bfloat16)")
     B, L, D = hidden_states.shape
@@ -367,6 +366,8 @@ class EagleTrainer:
         self.sched_step = 0
         self._pversion = 0                                       # bumped by every optimizer step (transposed-weight cache key)
         self._buckets = self._make_buckets(bucket_names)
+        self.check_collectives = False                           # tests: drain the device and assert every async all-reduce completed before AdamW
+        self.collectives_launched = 0
         self._sums = torch.zeros(4, dtype=torch.float32, device=self.flat.device)
 
     # ------------------------------------------------------------------ layout helpers
@@ -480,7 +481,12 @@ class EagleTrainer:
                     ops.scale_(self.grad, coef)
                     self._wn_f32.mul_(coef[0])
         for w in works:
-            w.wait()
+            w.wait()                                                        # the current stream waits for the collective: AdamW is ordered behind it
+        self.collectives_launched = len(works)
+        if self.check_collectives and works:
+            torch.cuda.current_stream().synchronize()
+            if not all(w.is_completed() for w in works):
+                raise RuntimeError("a gradient all-reduce had not completed when the optimizer step was reached")
         self._optimizer_step()
         stats = self._sums.clone()
         if self.group is not None:

@@ -75,6 +75,7 @@ def attn_train_fwd(qkv, B, L, H, hd):
     return out.to(BF16), (lse / math.log(2.0)).float()
 
 
+@torch.enable_grad()          # called from inside autograd.Function.backward too, where grad mode is off
 def attn_train_bwd(qkv, out, dout, lse, B, L, H, hd, dqkv=None):
     x = qkv.float().detach().requires_grad_(True)
     q, k, v = _split(x, B, L, H, hd)
@@ -92,6 +93,7 @@ def rmsnorm(x, w, eps, want_rstd=False):
     return (y, rstd.reshape(-1)) if want_rstd else y
 
 
+@torch.enable_grad()
 def rmsnorm_bwd(dy, x, w, rstd, res=None, dw=None, accumulate_dw=False):
     xf, wf = x.float().detach().requires_grad_(True), w.float().detach().requires_grad_(True)
     eps = 1.0 / rstd[:, None] ** 2 - xf.detach().pow(2).mean(-1, keepdim=True)       # recover eps from the saved rstd
@@ -219,13 +221,18 @@ def rope_tables(head_dim, n_pos, base=10000.0, device=None):
     return ang.cos().to(BF16), ang.sin().to(BF16)
 
 
+def require_device(t, what):
+    """Test processes only: the host logic of the N > 1 drivers runs on CPU tensors under gloo."""
+    return None
+
+
 def install(monkeypatch_setattr=None):
     """Replace the kernel wrappers of eagle_amd.ops by the stand-ins above (test processes only)."""
     from eagle_amd import ops
     g = globals()
     for name in ("gemm_nt", "transpose", "embed_concat", "rope_qk_", "attn_train_fwd", "attn_train_bwd", "rmsnorm", "rmsnorm_bwd",
                  "silu_mul", "silu_mul_bwd", "colsum", "adamw_", "grad_clip_coef", "clip_value_", "scale_", "add_f32_bf16",
-                 "ce_partial", "ce_combine", "ce_smoothl1_bwd", "rope_tables"):
+                 "ce_partial", "ce_combine", "ce_smoothl1_bwd", "rope_tables", "require_device"):
         if monkeypatch_setattr is not None:
             monkeypatch_setattr(ops, name, g[name])
         else:

@@ -136,6 +136,58 @@ def _sharded_worker(rank, world, port):
         dist.destroy_process_group()
 
 
+def _ddp_worker(rank, world, port):
+    """The reference's own loop body (eagle/train.py:72, :92-101, :105-131) around the drop-in model: DistributedDataParallel
+    (what accelerate's prepare_model wraps it in), no_sync on all but the last micro-batch, the loss scaling of :124,
+    accelerate's backward (/ GA), clip_grad_value_ after every backward, AdamW."""
+    import contextlib
+    dist = _setup(rank, world, port)
+    try:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        from eagle_amd.train import eagle_loss
+        from oracle import train_step as ots
+        dims, wb, model, lm_head = _tiny(seed=9)
+        model.train()
+        ddp = DDP(model)                                                            # train.py:72 (accelerator.prepare_model)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.95))     # train.py:66
+        GA, clip = 2, 0.01
+        all_mbs = [[_batch(20 * r + i, dims) for i in range(GA)] for r in range(world)]
+        mbs = all_mbs[rank]
+        n = sum(mb["loss_mask"].sum() for mb in mbs).clone()
+        dist.all_reduce(n)                                                          # train.py:92-93
+        num_items = float(n)
+        holder = {}
+        for i, mb in enumerate(mbs):
+            ctx = ddp.no_sync if (i < len(mbs) - 1 and world > 1) else contextlib.nullcontext   # train.py:97-100
+            with ctx():
+                predict = ddp(mb["hidden_states"], input_ids=mb["input_ids"])       # train.py:105
+                loss = eagle_loss(predict, mb["target"], lm_head, mb["loss_mask"], 1.0, 0.1, holder)
+                loss = (loss * GA * world) / num_items                              # train.py:124
+                (loss / GA).backward()                                              # accelerator.backward divides by GA
+                torch.nn.utils.clip_grad_value_(model.parameters(), clip)           # train.py:127
+        g, tot = ots.accumulate_grads({k: v.float() for k, v in wb.items()}, dims, lm_head.float(),
+                                      [[_f32(mb) for mb in r] for r in all_mbs], "dp", 1.0, 0.1, clip)
+        assert tot["num"] == num_items
+        named = dict(model.named_parameters())
+        assert named["embed_tokens.weight"].grad is None
+        for k, ref in g.items():
+            assert named[k].grad is not None and _rel(named[k].grad, ref) < 5e-2, (k, _rel(named[k].grad, ref))
+        opt.step()
+        opt.zero_grad()
+        mine = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()])
+        other = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(other, mine)
+        assert all(torch.equal(o_, mine) for o_ in other)                           # identical parameters on every rank
+        moved = max(float((named[k].detach().float() - wb[k].float()).abs().max()) for k in g)
+        assert moved > 0
+    finally:
+        dist.destroy_process_group()
+
+
+def test_reference_loop_under_ddp_two_ranks_gloo():
+    mp.spawn(_ddp_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
 @pytest.mark.parametrize("ga", [1, 2])
 def test_dp_trainer_two_ranks_gloo(ga):
     mp.spawn(_dp_worker, args=(2, _free_port(), ga), nprocs=2, join=True)

@@ -353,8 +353,10 @@ def test_trainer_over_a_real_rccl_group_of_one_rank():
             model, wb, lm_head = make_model(seed=11)
             tr = T.EagleTrainer(model, lm_head.to(DEV), lr=1e-3, grad_clip=0.02, num_warmup_steps=2, num_training_steps=10,
                                 mode="dp", group=group, world_size=1)
+            tr.check_collectives = group is not None     # every async bucket all-reduce completed before AdamW
             for _ in range(2):
                 out = tr.step(mbs)
+            assert tr.collectives_launched == (len(tr._buckets) if group is not None else 0)
             torch.cuda.synchronize()
             res.append((tr.flat.clone(), out["sums"].clone(), out["num_items"]))
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and res[0][2] == res[1][2]
