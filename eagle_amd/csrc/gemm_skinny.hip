@@ -431,9 +431,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
 // for all of the block's rows (no per-tile-step re-read of x through L2: at 8 tokens that re-read
 // is half as many bytes again as the weight stream), the RMSNorm row statistics are computed once,
 // and the super-step loop is fully unrolled: stage parity, x fragment and refill target are static.
-template <int RT, int EPI, int NI, bool NT>
+template <int RT, int EPI, int NI, bool NT, int S = 2>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
-  static_assert((NI & 1) == 0, "two register stages alternate");
+  static_assert(NI % S == 0, "S register stages rotate through the NI super-steps of a tile-step");
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;
   constexpr int RPS = RTW * 16;
   __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][RT][64][4];
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   const bool do_norm = p.norm_eps > 0.f;
   const bool mvalid = r16 < p.M;
 
-  bf16x8 a[2][4][RT];
+  bf16x8 a[S][4][RT];
   auto load_w = [&](bf16x8 (&st)[4][RT], int ts, int it) {
     const int kb = (wave + SK_WAVES * it) << 7;
 #pragma unroll
@@ -461,8 +461,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
         st[s][t] = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * 32)) : *reinterpret_cast<const bf16x8*>(wp + s * 32);
     }
   };
-  load_w(a[0], 0, 0);
-  load_w(a[1], 0, 1);
+#pragma unroll
+  for (int st = 0; st < S; ++st) load_w(a[st], 0, st);
   // activation rows (possibly gathered: two dependent index loads) -> registers, once
   const bf16_t* xa;
   const bf16_t* xb;
@@ -513,9 +513,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it & 1][s][t], xk[it][s], acc[t], 0, 0, 0);
-      // refill this stage with the super-step two ahead (past the last tile-step: clamped rows)
-      load_w(a[it & 1], ts + (it + 2) / NI, (it + 2) % NI);
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it % S][s][t], xk[it][s], acc[t], 0, 0, 0);
+      // refill this stage with the super-step S ahead (past the last tile-step: clamped rows)
+      load_w(a[it % S], ts + (it + S) / NI, (it + S) % NI);
     }
     const int parity = ts & 1;
 #pragma unroll
@@ -570,8 +570,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
 static int g_skinny_variant = 3;    // 3: per-shape choice (default); 0: tile kernel, 1: streaming kernel, 2: register-resident x where legal
 static int g_sk_blocks_per_cu = 2;
 static int g_sk_min_rows = 16;
+static int g_sk_keepx_stages = 2;   // register stages of the keepx kernel (2 or 4)
+static int g_sk_keepx_bpc = 1;      // keepx workgroups per CU
+static int g_sk_keepx_rt = 0;       // 0: by shape; 1 / 2: forced 16-row weight tiles per tile-step (EPI_LINEAR)
+static int g_sk_silu_tile = 0;      // 1: SiLU*up projection of <= 16 rows on the tile kernel
 extern "C" void eagle_debug_set_skinny_variant(int v, int blocks_per_cu, int min_rows) {
-  g_skinny_variant = v;
+  g_skinny_variant = v & 15;                       // bits 4-7: keepx register stages, bits 8-11: keepx blocks per CU
+  if ((v >> 4) & 15) g_sk_keepx_stages = (v >> 4) & 15;
+  if ((v >> 8) & 15) g_sk_keepx_bpc = (v >> 8) & 15;
+  g_sk_keepx_rt = (v >> 12) & 3;
+  g_sk_silu_tile = (v >> 14) & 1;
   if (blocks_per_cu > 0) g_sk_blocks_per_cu = blocks_per_cu;
   if (min_rows > 0) g_sk_min_rows = min_rows;
 }
@@ -598,13 +606,19 @@ static bool sk_stream_nt(const SkinnyArgs& a, int epi) { (void)epi; return a.nt;
 
 template <int RT, int EPI>
 static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
-  int grid = sk_num_cus();                             // ~160 VGPRs: one 8-wave block per CU
+  int grid = sk_num_cus() * g_sk_keepx_bpc;
   int R = (a.N + grid - 1) / grid;
   if (R < 16) R = 16;
   R = (R + 3) & ~3;
   grid = (a.N + R - 1) / R;
-  if (sk_stream_nt(a, EPI)) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
-  else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  const bool nt = sk_stream_nt(a, EPI);
+  if (g_sk_keepx_stages == 4) {
+    if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+    else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  } else {
+    if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 2>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+    else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 2>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  }
   return eagle_check_launch();
 }
 
@@ -675,11 +689,14 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     int rc;
     const int var = skinny_variant();   // 3 = per-shape choice (measured); 0/1/2 force one kernel family
     const bool big = (epi == EPI_SILU_MUL) || N >= 8192;
-    if (mc <= 16 && K == 128 * SK_WAVES * 4 && (var == 2 || (var == 3 && big))) {
+    if (mc <= 16 && K == 128 * SK_WAVES * 4 && (var == 2 || (var == 3 && big)) && !(g_sk_silu_tile && epi == EPI_SILU_MUL)) {
       if (epi == EPI_SILU_MUL) rc = launch_skinny_keepx<2, EPI_SILU_MUL>(a, stream);
-      else if (N >= 8192) rc = launch_skinny_keepx<2, EPI_LINEAR>(a, stream);
+      // one 16-row weight tile per tile-step: 32 KB in flight per CU stream as fast as 64 KB and the shorter tile-step
+      // ends sooner (lm_head 32000 x 4096 from cold caches 52.2 -> 49.0 us, in-cycle 53.7 -> 52.4; tools/skinny_sweep.py)
+      else if (g_sk_keepx_rt == 2) rc = launch_skinny_keepx<2, EPI_LINEAR>(a, stream);
       else rc = launch_skinny_keepx<1, EPI_LINEAR>(a, stream);
-    } else if (mc <= 16 && (K & 127) == 0 && K >= 128 * SK_WAVES && (var == 1 || var == 2 || (var == 3 && K >= 8192))) {
+    } else if (mc <= 16 && (K & 127) == 0 && K >= 128 * SK_WAVES && (var == 1 || var == 2 || (var == 3 && K >= 8192)) &&
+               !(g_sk_silu_tile && epi == EPI_SILU_MUL)) {
       if (epi == EPI_SILU_MUL) rc = launch_skinny_stream<2, EPI_SILU_MUL>(a, stream);
       else if (N >= 8192) rc = launch_skinny_stream<2, EPI_LINEAR>(a, stream);
       else rc = launch_skinny_stream<1, EPI_LINEAR>(a, stream);
