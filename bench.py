@@ -340,7 +340,7 @@ def dynamic_leg(dev, steps=5, topk=8, draft=32, ctx=300, cycles=60, warm=6, plan
         graph, t0, len0 = None, None, None
         for c in range(n_cyc):
             if record:
-                t_tok, t_par = dr.tree_tok.cpu().tolist(), dr.tree_parent.cpu().tolist()
+                t_tok, t_par = dr.tree_tok[0].cpu().tolist(), dr.tree_parent[0].cpu().tolist()
                 node = 0
                 while float(torch.rand(1, generator=g)) < plant_prob:
                     kids = [n for n in range(1, draft) if t_par[n] == node]

@@ -45,6 +45,7 @@ SIGNATURES = {
     "eagle_rope_qk_bf16": (I, [P, L, P, P, P, I, L, I, I, I, I, P]),
     "eagle_topk_workspace_bytes": (L, [I, I, I]),
     "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P, L, P]),
+    "eagle_topk_vocab_grouped": (I, [P, L, I, I, I, I, P, P, P, I, L, P]),
     "eagle_topk_vocab_noalloc": (I, [P, L, I, I, I, I, P, P, P, L, P]),
     "eagle_topk_lse_vocab": (I, [P, L, I, I, I, P, P, P, P, P]),
     "eagle_tree_layout": (I, [P, I, I, I, I, P]),
@@ -54,9 +55,9 @@ SIGNATURES = {
     "eagle_kv_compact_bf16": (I, [P, L, L, I, I, I, P, I, P, P, I, P, P]),
     "eagle_gather_accepted_bf16": (I, [P, I, I, P, I, P, P, P, P, P, I, P]),
     "eagle_row_lse_bf16": (I, [P, L, I, I, P, P]),
-    "eagle_dyn_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
-    "eagle_dyn_finalize": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P]),
-    "eagle_dyn_accept": (I, [I, I, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "eagle_dyn_step": (I, [I, I, I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P]),
+    "eagle_dyn_finalize": (I, [I, I, I, P, P, P, P, P, P, P, P, P, I, P]),
+    "eagle_dyn_accept": (I, [I, I, P, P, P, P, P, P, P, P, P, P, P, P, I, P]),
     "eagle_ce_stat_bytes": (I, []),
     "eagle_ce_partial_bf16": (I, [P, P, L, I, I, I, P, P, I, P, P]),
     "eagle_ce_combine": (I, [P, I, I, P, P, P, P, P, P]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "eagle_scale_bf16": (I, [P, L, P, P]),
     "eagle_add_f32_bf16": (I, [P, P, P, L, P]),
     "eagle_make_eagle_input_bf16": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "eagle_input_embed_concat_bf16": (I, [P, L, L, P, L, P, I, F, F, ctypes.c_uint64, ctypes.c_uint64, P, P, P, P, I, I, I, P]),
     "eagle_debug_set_gemm8": (None, [I]),
     "eagle_debug_set_skinny_variant": (None, [I, I, I]),
 }

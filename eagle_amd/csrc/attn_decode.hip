@@ -38,6 +38,8 @@ struct AttnDecArgs {
   int rows_per_req, row_off;  // row of request b, query m = b*rows_per_req + row_off + m
   int vec16;                  // hd % 16 == 0 and every base 16-byte aligned: 16-byte phase-0 accesses
   float sqrt_hd;
+  int split_keys;             // keys per partial record (64: attn_split_kernel; 512: attn_wide_kernel)
+  bf16_t* q_roped;            // wide path: [B][AD_MAXM][H*hd] roped queries (behind the partial records in the workspace)
 };
 
 // workspace record per (b, h, split): [AD_MAXM][AD_MAXHD] fp32 O~  then [AD_MAXM][2] fp32 (m, l)
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(2 * AD_MAXHD) void attn_combine_kernel(AttnDecArgs 
   const int M = p.M, hd = p.hd;
   const int past = p.past_len[b] + p.past_off;
   const int total = past + M;
-  const int ns = (total + AD_CH - 1) / AD_CH;
+  const int ns = (total + p.split_keys - 1) / p.split_keys;
   if (past < 0 || total > p.cap || ns > p.max_splits || m >= M) return;
   const float* base = p.ws + (int64_t)(b * p.H + h) * p.max_splits * AD_REC;
   float mx = -INFINITY, l = 0.f, o = 0.f;
@@ -356,8 +358,233 @@ __global__ __launch_bounds__(2 * AD_MAXHD) void attn_combine_kernel(AttnDecArgs 
     p.out[((int64_t)b * p.rows_per_req + p.row_off + m) * p.ld_out + h * hd + d] = f2bf(l > 0.f ? o / l : 0.f);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Wide batches (BASELINE configs[3]: 32 ragged requests x 32 heads): the 64-key workgroups above are chains of
+// memory latencies with P.V on the VALU (PMC: 61 % VALU-busy, waves waiting half their cycles) and every (b, h, chunk)
+// repeats the RoPE of its queries.  Here RoPE + append is one small pre-pass, and a workgroup takes up to 512 keys
+// of one (request, head): each of its 4 waves walks its own 32-key tiles with a private online softmax --
+//   K rows   HBM/L2 -> VGPR as MFMA A fragments (keys x queries, v_mfma_f32_16x16x32_bf16), one tile ahead,
+//   V rows   HBM/L2 -> LDS by LDS-DMA into the wave's own double buffer (row-major, 16-byte chunks XOR-swizzled),
+//            read back TRANSPOSED (ds_read_b64_tr_b16) as the A operand of O^T += V^T . P^T on MFMA,
+// no workgroup barrier inside the loop; the four partial states merge once through LDS into one partial record per
+// 512 keys (an eighth of the records the combine pass has to read).
+#define AW_TK 32
+#define AW_SPLIT 512
+typedef __attribute__((ext_vector_type(4))) short aw_s4;
+__device__ __forceinline__ int aw_off(int row, int ch) {   // byte offset of 16-byte chunk ch of row (0..31) in a V tile image
+  return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+// grid (ceil(rows*(H+2HK)*hd/8 / 256)): RoPE of q -> q_roped, RoPE of k and v -> cache rows [past, past+M)
+__global__ __launch_bounds__(256) void attn_rope_append_kernel(AttnDecArgs p) {
+  const int hd = p.hd, cpr = hd >> 3, nh = p.H + 2 * p.HK, half = hd >> 1;
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t per_req = (int64_t)p.M * nh * cpr;
+  if (item >= per_req * p.B) return;
+  const int b = (int)(item / per_req);
+  int rem = (int)(item - (int64_t)b * per_req);
+  const int m = rem / (nh * cpr); rem -= m * nh * cpr;
+  const int hh = rem / cpr, d0 = (rem - hh * cpr) << 3;
+  const int past = p.past_len[b] + p.past_off;
+  if (past < 0 || past + p.M > p.cap || (past + p.M + p.split_keys - 1) / p.split_keys > p.max_splits) {
+    if (p.err_flag) atomicExch(p.err_flag, 1);
+    return;
+  }
+  const int64_t row = (int64_t)b * p.rows_per_req + p.row_off + m;
+  const bf16_t* src = p.qkv + row * p.ld_qkv + (int64_t)hh * hd;
+  const uint4 xv = *reinterpret_cast<const uint4*>(src + d0);
+  uint4 o = xv;
+  if (hh < p.H + p.HK) {                     // q and k heads: x*cos + rotate_half(x)*sin with the reference's bf16 roundings
+    int64_t ps = p.pos ? p.pos[row] : (int64_t)past + p.pos_off + (int64_t)m * p.pos_stride;
+    ps = ps < 0 ? 0 : (ps >= p.n_pos ? p.n_pos - 1 : ps);
+    const bool lo = d0 < half;
+    const uint4 xp = *reinterpret_cast<const uint4*>(src + (lo ? d0 + half : d0 - half));
+    const uint4 cv = *reinterpret_cast<const uint4*>(p.cos_t + ps * hd + d0);
+    const uint4 sv = *reinterpret_cast<const uint4*>(p.sin_t + ps * hd + d0);
+    const uint32_t* aw = reinterpret_cast<const uint32_t*>(&xv);
+    const uint32_t* pw = reinterpret_cast<const uint32_t*>(&xp);
+    const uint32_t* cw = reinterpret_cast<const uint32_t*>(&cv);
+    const uint32_t* sw = reinterpret_cast<const uint32_t*>(&sv);
+    uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r0 = lo_bf(pw[j]), r1 = hi_bf(pw[j]);
+      if (lo) { r0 = -r0; r1 = -r1; }
+      ow[j] = pack2bf(rbf(lo_bf(aw[j]) * lo_bf(cw[j])) + rbf(r0 * lo_bf(sw[j])), rbf(hi_bf(aw[j]) * hi_bf(cw[j])) + rbf(r1 * hi_bf(sw[j])));
+    }
+  }
+  if (hh < p.H) {
+    *reinterpret_cast<uint4*>(p.q_roped + ((int64_t)b * AD_MAXM + m) * p.H * hd + (int64_t)hh * hd + d0) = o;
+  } else {
+    const bool isv = hh >= p.H + p.HK;
+    const int hk = hh - p.H - (isv ? p.HK : 0);
+    bf16_t* c = (isv ? p.vcache : p.kcache) + (int64_t)b * p.c_bstride + (int64_t)hk * p.c_hstride;
+    *reinterpret_cast<uint4*>(c + (int64_t)(past + m) * hd + d0) = o;
+  }
+}
+
+// grid (max_splits, H, B); hd = 128.  Reads q from q_roped and every key / value row (this call's included) from the cache.
+__global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[4][2][AW_TK * 256];      // per wave: two V tiles; reused for the merge
+  __shared__ float wm[4][AD_MAXM], wl[4][AD_MAXM];
+  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int M = p.M, hd = 128;
+  const int rep = p.H / p.HK, hk = h / rep;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g = lane >> 4;
+  const int past = p.past_len[b] + p.past_off;
+  const int total = past + M;
+  if (past < 0 || total > p.cap || (total + AW_SPLIT - 1) / AW_SPLIT > p.max_splits) return;   // flagged by the pre-pass
+  const int c_begin = split * AW_SPLIT;
+  if (c_begin >= total) return;
+  const int c_end = min(c_begin + AW_SPLIT, total);
+  const int n_wt = (c_end - c_begin + AW_TK - 1) / AW_TK;
+  const bf16_t* kc = p.kcache + (int64_t)b * p.c_bstride + (int64_t)hk * p.c_hstride;
+  const bf16_t* vc = p.vcache + (int64_t)b * p.c_bstride + (int64_t)hk * p.c_hstride;
+  const uint8_t* tm = p.tree_mask ? p.tree_mask + (int64_t)b * p.tm_bstride : nullptr;
+  const uint8_t* pm = p.pad_mask ? p.pad_mask + (int64_t)b * p.pm_stride : nullptr;
+  const int tree0 = total - p.T;
+  const int m = r16;                         // this lane's query (MFMA column)
+
+  bf16x8 qf[4];
+  {
+    const bf16_t* qrow = p.q_roped + ((int64_t)b * AD_MAXM + (m < M ? m : 0)) * p.H * hd + (int64_t)h * hd;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 32 * s + 8 * g);   // rows >= M: masked below
+  }
+  f32x4 o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrun = -INFINITY, lrun = 0.f;
+  const int tq = (lane & 15) >> 2, tp = lane & 3;
+
+  // V tile -> this wave's LDS buffer (8 wave-instructions of 1 KB = 4 rows each), then the K fragments of the tile
+  auto issue = [&](bf16x8 (&kf)[2][4], int buf, int wt) {
+    const int k0 = c_begin + wt * AW_TK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int trow = 4 * i + (lane >> 4), slot = lane & 15;
+      const int ch = slot ^ (((trow & 3) << 2) | ((trow >> 2) & 3));
+      const int row = min(k0 + trow, total - 1);                       // never predicated: rows past the end are masked
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vc + (int64_t)row * hd + ch * 8),
+                                       (__attribute__((address_space(3))) void*)&lds[wave][buf][i * 1024], 16, 0, 0);
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      const int row = min(k0 + 16 * kt + r16, total - 1);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) kf[kt][s] = *reinterpret_cast<const bf16x8*>(kc + (int64_t)row * hd + 32 * s + 8 * g);
+    }
+  };
+  auto compute = [&](const bf16x8 (&kf)[2][4], int buf, int wt) {
+    const int k0 = c_begin + wt * AW_TK;
+    f32x4 sc[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][s], qf[s], sc[kt], 0, 0, 0);
+    }
+    // V^T fragments (the tile has landed: the caller waited); requested ahead of the softmax arithmetic
+    const char* Vt = &lds[wave][buf][0];
+    bf16x8 vfr[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      const int r0 = 4 * g + tq;
+      const aw_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) aw_s4*)(Vt + aw_off(r0, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
+      const aw_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) aw_s4*)(Vt + aw_off(r0 + 16, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
+      union { struct { aw_s4 a, b; } s; bf16x8 v; } u;
+      u.s.a = lo; u.s.b = hi;
+      vfr[dt] = u.v;
+    }
+    float x[8], mx = mrun;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cc = k0 + 16 * kt + 4 * g + r;
+        bool vis = (m < M) && (cc < c_end);
+        if (p.causal && M > 1) vis = vis && (cc <= past + m);
+        if (pm && vis) vis = pm[cc] != 0;
+        if (tm && vis && cc >= tree0) vis = tm[m * p.T + (cc - tree0)] != 0;
+        x[4 * kt + r] = vis ? rbf(rbf(sc[kt][r]) / p.sqrt_hd) : -INFINITY;     // the reference's bf16 roundings of the scores
+        mx = fmaxf(mx, x[4 * kt + r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float ps = 0.f;
+    f32x4 p0, p1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p0[r] = (mx > -INFINITY) ? __expf(x[r] - mx) : 0.f;
+      p1[r] = (mx > -INFINITY) ? __expf(x[4 + r] - mx) : 0.f;
+      ps += p0[r] + p1[r];
+    }
+    if (__builtin_amdgcn_ballot_w64(mx != mrun)) {                    // wave-uniform: some query's maximum moved
+      const float alpha = (mrun > -INFINITY) ? __expf(mrun - mx) : 0.f;
+      lrun *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) o[dt] *= alpha;
+      mrun = mx;
+    }
+    lrun += ps;
+    bf16x8 pf;                                                         // k-slot (g, j) <-> key 16*(j>>2) + 4g + (j&3)
+    pf[0] = (__bf16)p0[0]; pf[1] = (__bf16)p0[1]; pf[2] = (__bf16)p0[2]; pf[3] = (__bf16)p0[3];
+    pf[4] = (__bf16)p1[0]; pf[5] = (__bf16)p1[1]; pf[6] = (__bf16)p1[2]; pf[7] = (__bf16)p1[3];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[dt], pf, o[dt], 0, 0, 0);
+  };
+
+  bf16x8 kfa[2][4], kfb[2][4];
+  int wt = wave;
+  if (wt < n_wt) {
+    issue(kfa, 0, wt);
+    while (true) {
+      int nxt = wt + 4;
+      bool has = nxt < n_wt;                                           // wave-uniform
+      if (has) { issue(kfb, 1, nxt); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      compute(kfa, 0, wt);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this tile's LDS reads are done before its buffer is refilled
+      if (!has) break;
+      wt = nxt; nxt = wt + 4; has = nxt < n_wt;
+      if (has) { issue(kfa, 0, nxt); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      compute(kfb, 1, wt);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (!has) break;
+      wt = nxt;
+    }
+  }
+  // ---- merge the four waves' (m, l, O~) through LDS; one partial record per workgroup ----
+  lrun += __shfl_xor(lrun, 16, 64);
+  lrun += __shfl_xor(lrun, 32, 64);
+  __syncthreads();                                                    // every wave is done with its V buffers
+  float* ow = reinterpret_cast<float*>(&lds[wave][0][0]);             // [16 queries][128 d] fp32 = 8 KB
+#pragma unroll
+  for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(ow + m * 128 + 16 * dt + 4 * g) = o[dt];
+  if (g == 0) { wm[wave][m] = mrun; wl[wave][m] = lrun; }
+  __syncthreads();
+  float* rec = p.ws + ((int64_t)(b * p.H + h) * p.max_splits + split) * AD_REC;
+  for (int i = t; i < M * 128; i += AD_THREADS) {
+    const int mm = i >> 7, d = i & 127;
+    float mx = fmaxf(fmaxf(wm[0][mm], wm[1][mm]), fmaxf(wm[2][mm], wm[3][mm]));
+    float acc = 0.f, l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float sc = (wm[w][mm] > -INFINITY) ? __expf(wm[w][mm] - mx) : 0.f;
+      acc += sc * reinterpret_cast<const float*>(&lds[w][0][0])[mm * 128 + d];
+      l += sc * wl[w][mm];
+    }
+    rec[mm * AD_MAXHD + d] = acc;
+    if (d == 0) { rec[AD_MAXM * AD_MAXHD + 2 * mm] = mx; rec[AD_MAXM * AD_MAXHD + 2 * mm + 1] = l; }
+  }
+}
+
 extern "C" int64_t eagle_attn_decode_workspace_bytes(int B, int H, int max_kv) {
-  return (int64_t)B * H * ((max_kv + AD_CH - 1) / AD_CH) * AD_REC * sizeof(float);
+  return (int64_t)B * H * ((max_kv + AD_CH - 1) / AD_CH) * AD_REC * sizeof(float)      // partial records (64-key form: the larger)
+         + (int64_t)B * AD_MAXM * H * AD_MAXHD * sizeof(bf16_t);                        // roped queries of the wide-batch path
 }
 
 // See include/eagle_hip.h for the contract.
@@ -391,6 +618,24 @@ extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const 
   a.vec16 = ((hd & 15) == 0) && ((cache_batch_stride & 7) == 0) &&
             (((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(cos_table) | reinterpret_cast<uintptr_t>(sin_table) |
                reinterpret_cast<uintptr_t>(kcache) | reinterpret_cast<uintptr_t>(vcache)) & 15) == 0);
+  a.split_keys = AD_CH;
+  a.q_roped = nullptr;
+  // wide batches: enough (request, head) pairs to fill the chip without 64-key workgroups
+  if (hd == 128 && a.vec16 && (int64_t)B * H >= 256) {
+    a.split_keys = AW_SPLIT;
+    a.max_splits = (max_kv + AW_SPLIT - 1) / AW_SPLIT;
+    a.q_roped = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(workspace) +
+                                          (int64_t)B * H * ((max_kv + AD_CH - 1) / AD_CH) * AD_REC * sizeof(float));
+    const int64_t items = (int64_t)B * M * (H + 2 * HK) * (hd / 8);
+    hipLaunchKernelGGL(attn_rope_append_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, a);
+    int rc = eagle_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_wide_kernel, dim3(a.max_splits, H, B), dim3(AD_THREADS), 0, stream, a);
+    rc = eagle_check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B, (M + 1) / 2), dim3(2 * AD_MAXHD), 0, stream, a);
+    return eagle_check_launch();
+  }
   const dim3 grid(a.max_splits, H, B), block(AD_THREADS);
   if (hd != 128) hipLaunchKernelGGL((attn_split_kernel<AD_MAXM, 0>), grid, block, 0, stream, a);
   else if (M <= 4) hipLaunchKernelGGL((attn_split_kernel<4, 128>), grid, block, 0, stream, a);

@@ -11,7 +11,7 @@
 //             (the k children of each of the k frontier nodes), in production order.
 //   score   = product of softmax probabilities along the path (fp32).
 //   order   = score descending, pool index ascending (a parent always precedes its children).
-// One request per launch (batch 1); all kernels are one workgroup of integer / small fp work.
+// One workgroup per request (grid = B independent requests, every per-request array is [B][...] contiguous); integer / small fp work.
 #include "common.h"
 
 #define DT_MAXK 16
@@ -88,11 +88,19 @@ __global__ __launch_bounds__(256) void dyn_step_kernel(int step, int k, int last
                                                        int64_t* __restrict__ pool_tok, float* __restrict__ pool_score,
                                                        int32_t* __restrict__ pool_parent, int64_t* __restrict__ ftok,
                                                        float* __restrict__ fscore_out, int32_t* __restrict__ fpool_out,
-                                                       int64_t* __restrict__ parent_row, uint8_t* __restrict__ mask_out) {
+                                                       int64_t* __restrict__ parent_row, uint8_t* __restrict__ mask_out, int P) {
   __shared__ float sc[DT_MAXK * DT_MAXK];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, b = blockIdx.x;
   const int R = step == 0 ? 1 : k, n = R * k;
   const int base = step == 0 ? 0 : k + (step - 1) * k * k;
+  // request b's slices
+  vals += (int64_t)b * n; ids += (int64_t)b * n; lse += (int64_t)b * R;
+  pool_tok += (int64_t)b * P; pool_score += (int64_t)b * P; pool_parent += (int64_t)b * P;
+  if (fscore_in) fscore_in += (int64_t)b * k;
+  if (fpool_in) fpool_in += (int64_t)b * k;
+  if (mask_in) mask_in += (int64_t)b * k * (step * k);
+  if (ftok) { ftok += (int64_t)b * k; fscore_out += (int64_t)b * k; fpool_out += (int64_t)b * k; parent_row += (int64_t)b * k;
+              mask_out += (int64_t)b * k * ((step + 1) * k); }
   if (t < n) {
     const int j = t / k;
     const float p = __expf(bf2f(vals[t]) - lse[j]);
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256) void dyn_step_kernel(int step, int k, int last
   ftok[rank] = ids[t];
   fscore_out[rank] = s;
   fpool_out[rank] = base + t;
-  parent_row[rank] = step == 0 ? root_row[0] : (int64_t)j;
+  parent_row[rank] = step == 0 ? root_row[b] : (int64_t)b * k + j;      // row of the previous (batched) forward
   const int w_in = step * k, w_out = (step + 1) * k;
   for (int c = 0; c < w_out; ++c) {
     uint8_t v = 0;
@@ -126,16 +134,17 @@ extern "C" int eagle_dyn_step(int step, int k, int last, const void* vals, const
                               const float* fscore_in, const int32_t* fpool_in, const uint8_t* mask_in,
                               const int64_t* root_row, int64_t* pool_tok, float* pool_score, int32_t* pool_parent,
                               int64_t* ftok, float* fscore_out, int32_t* fpool_out, int64_t* parent_row,
-                              uint8_t* mask_out, hipStream_t stream) {
+                              uint8_t* mask_out, int S, int B, hipStream_t stream) {
   if (!vals || !ids || !lse || !pool_tok || !pool_score || !pool_parent) return EAGLE_ERR_ARG;
-  if (step < 0 || k < 1 || k > DT_MAXK) return EAGLE_ERR_SHAPE;
+  if (step < 0 || k < 1 || k > DT_MAXK || B < 1 || S < 1 || step >= S) return EAGLE_ERR_SHAPE;
   if (step > 0 && (!fscore_in || !fpool_in)) return EAGLE_ERR_ARG;
   if (!last && (!ftok || !fscore_out || !fpool_out || !parent_row || !mask_out || (step > 0 && !mask_in) ||
                 (step == 0 && !root_row))) return EAGLE_ERR_ARG;
-  if ((step == 0 ? 0 : k + (step - 1) * k * k) + (step == 0 ? k : k * k) > DT_MAXP) return EAGLE_ERR_SHAPE;
-  hipLaunchKernelGGL(dyn_step_kernel, dim3(1), dim3(256), 0, stream, step, k, last, (const bf16_t*)vals, ids, lse, fscore_in,
+  const int P = k + (S - 1) * k * k;
+  if (P > DT_MAXP) return EAGLE_ERR_SHAPE;
+  hipLaunchKernelGGL(dyn_step_kernel, dim3(B), dim3(256), 0, stream, step, k, last, (const bf16_t*)vals, ids, lse, fscore_in,
                      fpool_in, mask_in, root_row, pool_tok, pool_score, pool_parent, ftok, fscore_out, fpool_out, parent_row,
-                     mask_out);
+                     mask_out, P);
   return eagle_check_launch();
 }
 
@@ -152,7 +161,10 @@ __global__ __launch_bounds__(256) void dyn_finalize_kernel(int k, int P, int T, 
   __shared__ float sc[DT_MAXP];
   __shared__ int16_t node_of[DT_MAXP];       // 0: not selected, else node id
   __shared__ int32_t par[DT_MAXT];
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, b = blockIdx.x;
+  pool_tok += (int64_t)b * P; pool_score += (int64_t)b * P; pool_parent += (int64_t)b * P; root_token += b;
+  tree_tok += (int64_t)b * T; tree_parent += (int64_t)b * T; tree_pos += (int64_t)b * T; tree_mask += (int64_t)b * T * T;
+  sel += (int64_t)b * (T - 1);
   for (int p = t; p < P; p += 256) sc[p] = pool_score[p];
   __syncthreads();
   for (int p = t; p < P; p += 256) {
@@ -196,13 +208,13 @@ __global__ __launch_bounds__(256) void dyn_finalize_kernel(int k, int P, int T, 
 extern "C" int eagle_dyn_finalize(int k, int S, int T, const int64_t* pool_tok, const float* pool_score,
                                   const int32_t* pool_parent, const int64_t* root_token, int64_t* tree_tok,
                                   int32_t* tree_parent, int64_t* tree_pos, uint8_t* tree_mask, int32_t* sel,
-                                  hipStream_t stream) {
+                                  int B, hipStream_t stream) {
   if (!pool_tok || !pool_score || !pool_parent || !root_token || !tree_tok || !tree_parent || !tree_pos || !tree_mask || !sel)
     return EAGLE_ERR_ARG;
-  if (k < 1 || k > DT_MAXK || S < 1) return EAGLE_ERR_SHAPE;
+  if (k < 1 || k > DT_MAXK || S < 1 || B < 1) return EAGLE_ERR_SHAPE;
   const int P = k + (S - 1) * k * k;
   if (P > DT_MAXP || T < 2 || T > DT_MAXT || T - 1 > P) return EAGLE_ERR_SHAPE;
-  hipLaunchKernelGGL(dyn_finalize_kernel, dim3(1), dim3(256), 0, stream, k, P, T, pool_tok, pool_score, pool_parent, root_token,
+  hipLaunchKernelGGL(dyn_finalize_kernel, dim3(B), dim3(256), 0, stream, k, P, T, pool_tok, pool_score, pool_parent, root_token,
                      tree_tok, tree_parent, tree_pos, tree_mask, sel);
   return eagle_check_launch();
 }
@@ -222,8 +234,11 @@ __global__ __launch_bounds__(64) void dyn_accept_kernel(int T, int W, const int6
                                                        int32_t* __restrict__ len_cur, int32_t* __restrict__ len_nxt,
                                                        int64_t* __restrict__ cursor) {
   __shared__ int pth[64];
-  const int lane = threadIdx.x;
-  if (cursor && lane == 0) { const int64_t c = cursor[0]; cursor[1] = c; cursor[0] = c + 1; }
+  const int lane = threadIdx.x, b = blockIdx.x;
+  if (cursor && lane == 0 && b == 0) { const int64_t c = cursor[0]; cursor[1] = c; cursor[0] = c + 1; }
+  tree_tok += (int64_t)b * T; tree_parent += (int64_t)b * T; target_argmax += (int64_t)b * T;
+  path += (int64_t)b * W; result += (int64_t)b * 4;
+  if (next_ids) next_ids += (int64_t)b * W;
   const int64_t tok = lane < T ? tree_tok[lane] : -1;
   const int par = lane < T ? tree_parent[lane] : -2;
   int cur = 0, alen = 0;
@@ -239,10 +254,10 @@ __global__ __launch_bounds__(64) void dyn_accept_kernel(int T, int W, const int6
   if (lane == 0) {
     const int64_t nxt = target_argmax[cur];
     for (int j = alen + 1; j < W; ++j) path[j] = -1;
-    result[0] = 0; result[1] = alen; result[2] = nxt; result[3] = (prev_len ? prev_len[0] : 0) + alen + 1;
-    if (n_acc) n_acc[0] = alen + 1;
-    if (last_idx) last_idx[0] = alen;
-    if (len_cur && len_nxt) { const int32_t l = len_nxt[0]; len_cur[0] = l; len_nxt[0] = l + alen + 1; }
+    result[0] = 0; result[1] = alen; result[2] = nxt; result[3] = (prev_len ? prev_len[b] : 0) + alen + 1;
+    if (n_acc) n_acc[b] = alen + 1;
+    if (last_idx) last_idx[b] = (int64_t)b * W + alen;                  // row of the next (batched, W rows per request) catch-up forward
+    if (len_cur && len_nxt) { const int32_t l = len_nxt[b]; len_cur[b] = l; len_nxt[b] = l + alen + 1; }
   }
   if (next_ids) {
     // lane j < alen: token of the (j+1)-th accepted node; lane alen: the verifier's next token
@@ -259,10 +274,10 @@ __global__ __launch_bounds__(64) void dyn_accept_kernel(int T, int W, const int6
 extern "C" int eagle_dyn_accept(int T, int W, const int64_t* tree_tok, const int32_t* tree_parent,
                                 const int64_t* target_argmax, const int32_t* prev_len, int64_t* path, int64_t* result,
                                 int64_t* next_ids, int32_t* n_acc, int64_t* last_idx, int32_t* len_cur, int32_t* len_nxt,
-                                int64_t* cursor, hipStream_t stream) {
+                                int64_t* cursor, int B, hipStream_t stream) {
   if (!tree_tok || !tree_parent || !target_argmax || !path || !result) return EAGLE_ERR_ARG;
-  if (T < 1 || T > DT_MAXT || W < 1 || W > 64) return EAGLE_ERR_SHAPE;
-  hipLaunchKernelGGL(dyn_accept_kernel, dim3(1), dim3(64), 0, stream, T, W, tree_tok, tree_parent, target_argmax, prev_len, path,
+  if (T < 1 || T > DT_MAXT || W < 1 || W > 64 || B < 1) return EAGLE_ERR_SHAPE;
+  hipLaunchKernelGGL(dyn_accept_kernel, dim3(B), dim3(64), 0, stream, T, W, tree_tok, tree_parent, target_argmax, prev_len, path,
                      result, next_ids, n_acc, last_idx, len_cur, len_nxt, cursor);
   return eagle_check_launch();
 }

@@ -149,6 +149,127 @@ __global__ __launch_bounds__(GM_THREADS) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Decode batches (32-192 rows against a very tall weight matrix: the lm_head of a batch-32 tree step, eagle/train.py:
+// 215-228 applied to draft rows): the launch is a weight stream, and the kernel above keeps only ONE K step in flight
+// per workgroup and drains it at every barrier, so a K step costs a memory latency (1.9 us measured: 4.5 TB/s).
+// Same tile math, different pipeline: BM = 32 / 64 / 128 activation rows (no MFMA work on padding rows), BN = 128
+// weight rows, S LDS stages filled by LDS-DMA that stay in flight across the (single) barrier of a K step behind a
+// counted vmcnt -- S-1 K steps of weights in flight per workgroup.
+template <int BM, int S, int BN = GM_BN, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_rows_kernel(GemmArgs p) {
+  constexpr int NT = NW * 64;
+  constexpr int WM = BM == 128 ? 2 : 1, WN = NW / WM;           // wave grid
+  constexpr int I = BM / WM / 16, J = BN / WN / 16;              // 16x16 tiles per wave
+  constexpr int A_OPS = BM * 8 / NT, B_OPS = BN * 8 / NT, OPS = A_OPS + B_OPS;
+  constexpr int STAGE = (BM + BN) * GM_BK;                       // elements
+  extern __shared__ __attribute__((aligned(16))) bf16_t dyn_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int wm = WM == 2 ? wave / WN : 0, wn = WM == 2 ? (wave % WN) : wave;
+  const int tn = blockIdx.x / p.tiles_m, tm = blockIdx.x - tn * p.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  auto stage = [&](int buf, int kt) {
+    bf16_t* la = dyn_lds + buf * STAGE;
+    bf16_t* lb = la + BM * GM_BK;
+#pragma unroll
+    for (int i = 0; i < A_OPS; ++i) {
+      const int L = i * NT + tid, row = L >> 3, slot = L & 7, chunk = slot ^ (row & 7);
+      int ra = m0 + row; ra = ra < p.M ? ra : p.M - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.A + (int64_t)ra * p.lda + kt * GM_BK + chunk * 8),
+                                       (__attribute__((address_space(3))) void*)(la + (i * NT + wave * 64) * 8), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_OPS; ++i) {
+      const int L = i * NT + tid, row = L >> 3, slot = L & 7, chunk = slot ^ (row & 7);
+      int rb = n0 + row; rb = rb < p.N ? rb : p.N - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.B + (int64_t)rb * p.ldb + kt * GM_BK + chunk * 8),
+                                       (__attribute__((address_space(3))) void*)(lb + (i * NT + wave * 64) * 8), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[I][J];
+#pragma unroll
+  for (int i = 0; i < I; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nk = p.K / GM_BK;
+  // prologue: S-1 stages in flight (past the end: re-reads of the last K step, never multiplied)
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) stage(s, s < nk ? s : nk - 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    // this thread's share of stage kt has landed when at most S-2 younger stages are outstanding ...
+    if (S == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (S == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+    __builtin_amdgcn_s_barrier();      // ... everybody's has, and everybody is done reading the buffer refilled next
+    const int nxt = kt + S - 1;
+    stage(nxt % S, nxt < nk ? nxt : nk - 1);
+    const bf16_t* la = dyn_lds + (kt % S) * STAGE;
+    const bf16_t* lb = la + BM * GM_BK;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 xf[I], wf[J];
+      const int c = 4 * s + g;
+#pragma unroll
+      for (int i = 0; i < I; ++i) {
+        const int ra = wm * (I * 16) + i * 16 + r16;
+        xf[i] = *reinterpret_cast<const bf16x8*>(la + ra * GM_BK + ((c ^ (ra & 7)) << 3));
+      }
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const int rb = wn * (J * 16) + j * 16 + r16;
+        wf[j] = *reinterpret_cast<const bf16x8*>(lb + rb * GM_BK + ((c ^ (rb & 7)) << 3));
+      }
+#pragma unroll
+      for (int i = 0; i < I; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (unused) refills land before the LDS is released
+  // epilogue: acc[i][j][r] = C[m0 + wm*I*16 + i*16 + r16][n0 + wn*J*16 + j*16 + 4g + r]; bf16 output (+bias) (+res)
+#pragma unroll
+  for (int i = 0; i < I; ++i) {
+    const int m = m0 + wm * (I * 16) + i * 16 + r16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int nb = n0 + wn * (J * 16) + j * 16 + 4 * g;
+      if (nb >= p.N) continue;
+      float y[4];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int n = nb + rr;
+        float v = acc[i][j][rr];
+        if (p.bias && n < p.N) v += bf2f(p.bias[n]);
+        if (p.res && n < p.N) v = rbf(v) + bf2f(p.res[(int64_t)m * p.ldr + n]);
+        y[rr] = v;
+      }
+      bf16_t* o = (bf16_t*)p.C + (int64_t)m * p.ldc + nb;
+      if ((nb + 3 < p.N) && ((p.ldc & 3) == 0)) *reinterpret_cast<uint2*>(o) = make_uint2(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]));
+      else for (int rr = 0; rr < 4; ++rr) if (nb + rr < p.N) o[rr] = f2bf(y[rr]);
+    }
+  }
+}
+
+static int g_rows_cfg = 0;     // 0: by shape; else (BM << 4 | S) forced (eagle_debug_set_gemm8 values >= 0x100 carry it)
+template <int BM, int S, int BN = GM_BN, int NW = 4>
+static int launch_rows(GemmArgs& a, hipStream_t stream) {
+  constexpr int bytes = S * (BM + BN) * GM_BK * 2;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_nt_rows_kernel<BM, S, BN, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return EAGLE_ERR_LAUNCH;
+    attr = true;
+  }
+  a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm_nt_rows_kernel<BM, S, BN, NW>), dim3(a.tiles_m * a.tiles_n), dim3(NW * 64), bytes, stream, a);
+  return eagle_check_launch();
+}
+
 static inline bool gm_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // gemm_mfma8.hip: 256x256 tiles, DMA in flight across barriers
@@ -156,7 +277,10 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
                           const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
                           void* workspace, hipStream_t stream);
 static int g_gemm8_mode = 2;    // 0: never, 1: whenever legal, 2: by shape (default); eagle_debug_set_gemm8
-extern "C" void eagle_debug_set_gemm8(int mode) { g_gemm8_mode = mode; }
+extern "C" void eagle_debug_set_gemm8(int mode) {
+  if (mode >= 0x100) { g_rows_cfg = mode & 0xfff; return; }     // 0x100 | BM<<4... see the header
+  g_gemm8_mode = mode;
+}
 static bool use_gemm8(int M, int N, int K) {
   if (g_gemm8_mode == 0 || K < 2 * GM_BK) return false;
   if (g_gemm8_mode == 1) return true;
@@ -179,6 +303,25 @@ extern "C" int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int
   if (use_gemm8(M, N, K))
     return eagle_launch_gemm_nt8(A, lda, B, ldb, C, ldc, bias, res, ldr, M, N, K, out_f32, accumulate, 1, nullptr, stream);
   GemmArgs a;
+  // decode batches against a tall weight matrix: the deep-pipelined row kernels (bf16 output, no accumulate)
+  if (g_gemm8_mode == 2 && (M <= 32 || (g_rows_cfg & 0xff)) && M <= 192 && N >= 8192 && K >= 4 * GM_BK && !out_f32 && !accumulate &&
+      g_rows_cfg != 0xfff) {
+    a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+    a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
+    a.M = M; a.N = N; a.K = K; a.out_f32 = 0; a.accumulate = 0;
+    const int cfg = g_rows_cfg & 0xff;
+    switch (cfg) {                                   // diagnostics: forced configuration (BM / 16) << 4 | S
+      case 0x23: return launch_rows<32, 3>(a, stream);
+      case 0x24: return launch_rows<32, 4>(a, stream);
+      case 0x43: return launch_rows<64, 3>(a, stream);
+      case 0x83: return launch_rows<128, 3>(a, stream);
+      case 0x93: return launch_rows<128, 3, 256, 8>(a, stream);      // 128 x 256 tiles, 8 waves
+      default: break;
+    }
+    // measured on the 151936 x 4096 head from cold caches (tools/rows_sweep.py): 32 rows 253 us against 265 us for the
+    // 128x128 kernel; at 64+ rows no configuration (deeper pipelines, 128x256 tiles) beats the 128x128 kernel's 295 us
+    if (M <= 32) return launch_rows<32, 3>(a, stream);
+  }
   a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
                                                                 int64_t* __restrict__ out_idx, T* __restrict__ out_val,
                                                                 const int64_t* __restrict__ block_index, int64_t block_rows,
                                                                 const float2* __restrict__ lse_part, int nwc,
-                                                                float* __restrict__ lse_out) {
+                                                                float* __restrict__ lse_out, int out_group, int64_t out_gstride) {
   __shared__ unsigned long long surv[4 * TK_MAXK];
   if (block_index) x += *block_index * block_rows * ld;
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -235,8 +235,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
   if (lane < k) {
     // fewer than k entries can only happen when V < k; emit index -1 then
     const int64_t idx = won ? (int64_t)(0xffffffffu - (uint32_t)(won & 0xffffffffu)) : -1;
-    out_idx[(int64_t)row * k + lane] = idx;
-    if (out_val) out_val[(int64_t)row * k + lane] = idx >= 0 ? x[(int64_t)row * ld + idx] : (T)0;
+    // output row: groups of out_group rows, out_gstride elements apart (out_group = 0: plain [rows, k])
+    const int64_t opos = out_group ? (int64_t)(row / out_group) * out_gstride + (int64_t)(row % out_group) * k : (int64_t)row * k;
+    out_idx[opos + lane] = idx;
+    if (out_val) out_val[opos + lane] = idx >= 0 ? x[(int64_t)row * ld + idx] : (T)0;
   }
 }
 
@@ -246,7 +248,8 @@ extern "C" int64_t eagle_topk_workspace_bytes(int rows, int V, int k) {
 }
 
 static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int V, int k, int64_t* out_idx, void* out_val,
-                       void* workspace, const int64_t* block_index, int64_t block_rows, float* lse_out, hipStream_t stream) {
+                       void* workspace, const int64_t* block_index, int64_t block_rows, float* lse_out, hipStream_t stream,
+                       int out_group = 0, int64_t out_gstride = 0) {
   if (!logits || !out_idx || !workspace) return EAGLE_ERR_ARG;
   if (block_index && block_rows < rows) return EAGLE_ERR_SHAPE;
   if (rows < 1 || V < 1 || k < 1 || k > TK_MAXK || ld < V) return EAGLE_ERR_SHAPE;
@@ -259,17 +262,17 @@ static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int 
     hipLaunchKernelGGL(topk_stage1_bf16_kernel<true>, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand,
                        block_index, block_rows, part);
     hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, true>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
-                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out);
+                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
   } else if (dtype == 0) {
     hipLaunchKernelGGL(topk_stage1_bf16_kernel<false>, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand,
                        block_index, block_rows, part);
     hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
-                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out);
+                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
   } else if (dtype == 1 && !lse_out) {
     hipLaunchKernelGGL(topk_stage1_f32_kernel, g1, dim3(TK_THREADS), 0, stream, (const float*)logits, ld, V, k, nwc, cand, block_index, block_rows);
     hipLaunchKernelGGL((topk_stage2_kernel<float, false>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                        (const float*)logits, ld, out_idx, (float*)out_val, block_index, block_rows, (const float2*)nullptr, nwc,
-                       (float*)nullptr);
+                       (float*)nullptr, out_group, out_gstride);
   } else {
     return EAGLE_ERR_ARG;
   }
@@ -281,6 +284,13 @@ extern "C" int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int r
                                 int64_t* out_idx, void* out_val, void* workspace, const int64_t* block_index,
                                 int64_t block_rows, hipStream_t stream) {
   return topk_launch(logits, ld, dtype, rows, V, k, out_idx, out_val, workspace, block_index, block_rows, nullptr, stream);
+}
+
+// eagle_topk_vocab writing into a batched table: logits row r = b*group + j goes to out + b*group_stride + j*k (elements)
+extern "C" int eagle_topk_vocab_grouped(const void* logits, int64_t ld, int dtype, int rows, int V, int k, int64_t* out_idx,
+                                        void* out_val, void* workspace, int group, int64_t group_stride, hipStream_t stream) {
+  if (group < 1 || rows % group || group_stride < (int64_t)group * k) return EAGLE_ERR_SHAPE;
+  return topk_launch(logits, ld, dtype, rows, V, k, out_idx, out_val, workspace, nullptr, 0, nullptr, stream, group, group_stride);
 }
 
 // bf16 logits: the top-k of eagle_topk_vocab plus lse_out[rows] = fp32 log-sum-exp of every row, from the same pass

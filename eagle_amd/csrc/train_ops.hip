@@ -242,6 +242,74 @@ __global__ __launch_bounds__(256) void make_eagle_input_kernel(const bf16_t* __r
   if (threadIdx.x == 0) ids_out[row] = (l < L - 1) ? ids[row + 1] : 0;
 }
 
+// ---- fused input path: _make_eagle_input (eagle/train.py:256-275) + the draft head's embedding gather / concat
+// (eagle/llama2.py:515, :537-542) in ONE pass over the verifier's hidden state ----
+// Philox4x32-10 (Salmon et al., SC'11): counter = (element index / 4, stream offset), key = seed; word j of the
+// output belongs to element 4*(index/4) + j.  u = (x >> 8) * 2^-24 in [0, 1).
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// One block per (b, l) row.  noisy = bf16(hidden + bf16(low + (high-low)*u)) (the reference draws the noise in the
+// hidden state's dtype and adds it in that dtype, train.py:272-275); x0[row] = cat(emb[ids[row+1] or 0], noisy[row]);
+// target[row-1] = noisy[row], target[last row of a sequence] = 0; ids_out = ids shifted left with trailing 0.
+__global__ __launch_bounds__(256) void eagle_input_fused_kernel(const bf16_t* __restrict__ hid, int64_t ldh_b, int64_t ldh_l,
+                                                               const int64_t* __restrict__ ids, int64_t ldi,
+                                                               const bf16_t* __restrict__ emb, int V, float low, float high,
+                                                               uint64_t seed, uint64_t offset, bf16_t* __restrict__ x0,
+                                                               bf16_t* __restrict__ target, int64_t* __restrict__ ids_out,
+                                                               bf16_t* __restrict__ noise_out, int L, int D) {
+  const int64_t row = blockIdx.x;
+  const int b = (int)(row / L), l = (int)(row - (int64_t)b * L);
+  int64_t id = (l < L - 1) ? ids[(int64_t)b * ldi + l + 1] : 0;
+  if (threadIdx.x == 0 && ids_out) ids_out[row] = id;
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  const bf16_t* hrow = hid + (int64_t)b * ldh_b + (int64_t)l * ldh_l;
+  const bool draw = high != low;
+  for (int c = threadIdx.x; c < (D >> 3); c += blockDim.x) {
+    float h[8];
+    ld8(hrow + c * 8, h);
+    if (draw) {
+      const uint64_t e = (uint64_t)row * (uint64_t)D + (uint64_t)c * 8;      // first of this thread's 8 elements
+      uint32_t r[8];
+      philox4x32_10((uint32_t)(e >> 2), (uint32_t)(e >> 34), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+      philox4x32_10((uint32_t)((e >> 2) + 1), (uint32_t)(((e >> 2) + 1) >> 32), (uint32_t)offset, (uint32_t)(offset >> 32), (uint32_t)seed,
+                    (uint32_t)(seed >> 32), r + 4);
+      float z[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        z[j] = rbf(fmaf((float)(r[j] >> 8) * 5.9604644775390625e-8f, high - low, low));
+        h[j] = h[j] + z[j];
+      }
+      if (noise_out) st8(noise_out + row * D + c * 8, z);
+    }
+    st8(x0 + row * 2 * D + D + c * 8, h);
+    if (l > 0) st8(target + (row - 1) * D + c * 8, h);
+    if (l == L - 1) { float zero[8] = {0, 0, 0, 0, 0, 0, 0, 0}; st8(target + row * D + c * 8, zero); }
+    *reinterpret_cast<uint4*>(x0 + row * 2 * D + c * 8) = *reinterpret_cast<const uint4*>(emb + id * D + c * 8);
+  }
+}
+
+extern "C" int eagle_input_embed_concat_bf16(const void* hidden, int64_t ldh_b, int64_t ldh_l, const int64_t* ids, int64_t ldi,
+                                             const void* emb, int V, float low, float high, uint64_t seed, uint64_t offset,
+                                             void* x0, void* target, int64_t* ids_out, void* noise_out, int B, int L, int D,
+                                             hipStream_t stream) {
+  if (!hidden || !ids || !emb || !x0 || !target) return EAGLE_ERR_ARG;
+  if (B < 1 || L < 1 || D < 8 || (D & 7) || V < 1 || (ldh_b & 7) || (ldh_l & 7) || ldh_l < D || ldi < L || !(high >= low)) return EAGLE_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(emb) | reinterpret_cast<uintptr_t>(x0) |
+       reinterpret_cast<uintptr_t>(target) | reinterpret_cast<uintptr_t>(noise_out)) & 15) return EAGLE_ERR_SHAPE;
+  hipLaunchKernelGGL(eagle_input_fused_kernel, dim3(B * L), dim3(256), 0, stream, (const bf16_t*)hidden, ldh_b, ldh_l, ids, ldi,
+                     (const bf16_t*)emb, V, low, high, seed, offset, (bf16_t*)x0, (bf16_t*)target, ids_out, (bf16_t*)noise_out, L, D);
+  return eagle_check_launch();
+}
+
 extern "C" int eagle_embed_concat_bf16(const void* emb, const int64_t* ids, const void* hidden, int64_t ldh, void* out, int N, int D,
                                        int V, hipStream_t stream) {
   if (!emb || !ids || !hidden || !out) return EAGLE_ERR_ARG;

@@ -66,3 +66,26 @@ def make_eagle_batch(batch: Dict[str, torch.Tensor], verifier_hidden: torch.Tens
         noise = noise[:, :max_model_len].to(device=dev, dtype=h.dtype)
     ho, tg, io = ops.make_eagle_input(h, ids, noise)
     return {"input_ids": io, "hidden_states": ho, "target": tg, "loss_mask": lm}
+
+
+def make_eagle_draft_input(batch: Dict[str, torch.Tensor], verifier_hidden: torch.Tensor, embed_weight: torch.Tensor,
+                           max_model_len: int, transform_uniform_low: float = 0.0, transform_uniform_high: float = 0.0,
+                           seed: int = 0, offset: int = 0, want_noise: bool = False) -> Dict[str, torch.Tensor]:
+    """``make_eagle_batch`` fused with the draft head's embedding gather + concat: one kernel reads the verifier's hidden
+    state once, draws the uniform noise on the fly (Philox4x32-10 keyed by ``seed``; pass a fresh ``offset`` per
+    micro-batch, e.g. the global micro-batch counter), shifts, and writes the fc input ``x0`` [B*L, 2D] and the
+    (noisy) ``target`` directly -- no noise tensor, no hidden_states copy, no separate embed_concat pass
+    (eagle/train.py:256-275 + eagle/llama2.py:515, :537-542).  The result feeds ``EagleTrainer.step`` (which takes
+    ``x0`` in place of hidden_states / input_ids for the forward)."""
+    dev = verifier_hidden.device
+    ids = batch["input_ids"].to(dev)
+    L = min(max_model_len, ids.shape[1], verifier_hidden.shape[1])
+    lm = batch["loss_mask"][:, :L].to(dev)
+    if verifier_hidden.shape[0] != ids.shape[0] or verifier_hidden.shape[1] < L:
+        raise ValueError(f"verifier_hidden {tuple(verifier_hidden.shape[:2])} does not cover input_ids {tuple(ids.shape)}")
+    x0, tg, io, noise = ops.eagle_input_embed_concat(verifier_hidden[:, :L], ids, embed_weight, transform_uniform_low,
+                                                     transform_uniform_high, seed, offset, want_noise)
+    out = {"input_ids": io, "x0": x0, "target": tg, "loss_mask": lm, "hidden_states": x0.view(ids.shape[0], L, -1)[:, :, x0.shape[1] // 2:]}
+    if want_noise:
+        out["noise"] = noise
+    return out

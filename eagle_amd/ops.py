@@ -233,6 +233,26 @@ def make_eagle_input(hidden: torch.Tensor, ids: torch.Tensor, noise: Optional[to
     return ho, tg, io
 
 
+def eagle_input_embed_concat(hidden: torch.Tensor, ids: torch.Tensor, emb: torch.Tensor, low: float = 0.0, high: float = 0.0,
+                             seed: int = 0, offset: int = 0, want_noise: bool = False):
+    """Fused _make_eagle_input + embedding gather/concat (include/eagle_hip.h: eagle_input_embed_concat_bf16).
+    hidden [B, L, D] bf16 (rows contiguous, any batch / row strides), ids [B, >= L] int64 unshifted.
+    Returns (x0 [B*L, 2D], target [B, L, D], ids_out [B, L], noise [B, L, D] or None)."""
+    _chk(hidden, "hidden"), _chk(emb, "emb")
+    B, L, D = hidden.shape
+    if hidden.stride(2) != 1 or ids.dtype != torch.int64 or not ids.is_cuda or ids.stride(1) != 1 or ids.shape[0] != B or ids.shape[1] < L:
+        raise ValueError("eagle_input_embed_concat: hidden [B, L, D] with contiguous rows, ids [B, >= L] int64 on the device")
+    dev = hidden.device
+    x0 = torch.empty((B * L, 2 * D), dtype=BF16, device=dev)
+    target = torch.empty((B, L, D), dtype=BF16, device=dev)
+    ids_out = torch.empty((B, L), dtype=torch.int64, device=dev)
+    noise = torch.zeros((B, L, D), dtype=BF16, device=dev) if want_noise else None
+    call("eagle_input_embed_concat_bf16", ptr(hidden), hidden.stride(0), hidden.stride(1), ptr(ids), ids.stride(0), ptr(emb),
+         emb.shape[0], float(low), float(high), int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), ptr(x0), ptr(target),
+         ptr(ids_out), ptr(noise), B, L, D, stream())
+    return x0, target, ids_out, noise
+
+
 def tree_attention(qkv: torch.Tensor, position_ids: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
                    kcache: torch.Tensor, vcache: torch.Tensor, past_len: torch.Tensor, past_off: int,
                    tree_mask: Optional[torch.Tensor], pad_mask: Optional[torch.Tensor], out: torch.Tensor,
@@ -341,6 +361,21 @@ def topk(logits: torch.Tensor, k: int, want_values: bool = True,
     call("eagle_topk_vocab", ptr(logits), logits.stride(0), dt, rows, V, k, ptr(out_idx),
          ptr(out_val) if want_values else None, ptr(ws), ptr(block_index), rows, stream())
     return (out_val if want_values else None), out_idx
+
+
+def topk_into_table(logits: torch.Tensor, k: int, table_idx: torch.Tensor, table_val: torch.Tensor, row0: int, n: int,
+                    workspace: torch.Tensor) -> None:
+    """top-k of logits [B*n, V] (request-major rows) written into table[:, row0:row0+n, :] of the [B, R, k] tables."""
+    _chk(logits, "logits")
+    rows, V = logits.shape
+    topk_limit_check(V, k)
+    B, R, kk = table_idx.shape
+    if kk != k or rows != B * n or not table_idx.is_contiguous() or not table_val.is_contiguous() or table_val.shape != table_idx.shape:
+        raise ValueError("topk_into_table: tables [B, R, k] contiguous, logits [B*n, V]")
+    if workspace.numel() * workspace.element_size() < query("eagle_topk_workspace_bytes", rows, V, k):
+        raise ValueError("topk: workspace too small")
+    call("eagle_topk_vocab_grouped", ptr(logits), logits.stride(0), 0, rows, V, k, table_idx.data_ptr() + row0 * k * 8,
+         table_val.data_ptr() + row0 * k * 2, ptr(workspace), n, R * k, stream())
 
 
 def first_argmax(logits: torch.Tensor) -> torch.Tensor:
@@ -539,19 +574,19 @@ def row_lse(logits: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
 
 
 def dyn_step(step: int, k: int, last: bool, vals, ids, lse, fscore_in, fpool_in, mask_in, root_row, pool_tok, pool_score,
-             pool_parent, ftok, fscore_out, fpool_out, parent_row, mask_out) -> None:
+             pool_parent, ftok, fscore_out, fpool_out, parent_row, mask_out, S: int, B: int = 1) -> None:
     call("eagle_dyn_step", step, k, int(last), ptr(vals), ptr(ids), ptr(lse), ptr(fscore_in), ptr(fpool_in), ptr(mask_in),
          ptr(root_row), ptr(pool_tok), ptr(pool_score), ptr(pool_parent), ptr(ftok), ptr(fscore_out), ptr(fpool_out),
-         ptr(parent_row), ptr(mask_out), stream())
+         ptr(parent_row), ptr(mask_out), S, B, stream())
 
 
 def dyn_finalize(k: int, S: int, T: int, pool_tok, pool_score, pool_parent, root_token, tree_tok, tree_parent, tree_pos,
-                 tree_mask, sel) -> None:
+                 tree_mask, sel, B: int = 1) -> None:
     call("eagle_dyn_finalize", k, S, T, ptr(pool_tok), ptr(pool_score), ptr(pool_parent), ptr(root_token), ptr(tree_tok),
-         ptr(tree_parent), ptr(tree_pos), ptr(tree_mask), ptr(sel), stream())
+         ptr(tree_parent), ptr(tree_pos), ptr(tree_mask), ptr(sel), B, stream())
 
 
 def dyn_accept(T: int, W: int, tree_tok, tree_parent, target_argmax, prev_len, path, result, next_ids=None, n_acc=None,
-               last_idx=None, len_cur=None, len_nxt=None, cursor=None) -> None:
+               last_idx=None, len_cur=None, len_nxt=None, cursor=None, B: int = 1) -> None:
     call("eagle_dyn_accept", T, W, ptr(tree_tok), ptr(tree_parent), ptr(target_argmax), ptr(prev_len), ptr(path), ptr(result),
-         ptr(next_ids), ptr(n_acc), ptr(last_idx), ptr(len_cur), ptr(len_nxt), ptr(cursor), stream())
+         ptr(next_ids), ptr(n_acc), ptr(last_idx), ptr(len_cur), ptr(len_nxt), ptr(cursor), B, stream())

@@ -109,10 +109,8 @@ class EagleDrafter:
         if self.B == 1:
             ops.topk(logits, self.k, out_idx=self.flat_ids[0, row0:row0 + n], out_val=self.flat_vals[0, row0:row0 + n],
                      workspace=self._ws)
-        else:
-            vals, ids = ops.topk(logits, self.k, workspace=self._ws)
-            self.flat_ids[:, row0:row0 + n] = ids.view(self.B, n, self.k)
-            self.flat_vals[:, row0:row0 + n] = vals.view(self.B, n, self.k)
+        else:                                     # straight into the [B, R, k] tables (no copy pass per step)
+            ops.topk_into_table(logits, self.k, self.flat_ids, self.flat_vals, row0, n, self._ws)
 
     def prefill(self, hidden: torch.Tensor, input_ids: torch.Tensor):
         """First call of a request batch: hidden [B, ctx, D] = verifier hidden states of the prompt,

@@ -114,9 +114,12 @@ class _TransposeCache:
 # forward / backward kernel chains
 # ---------------------------------------------------------------------------------------------
 def draft_fwd(W: LayerWeights, emb: torch.Tensor, ids: torch.Tensor, hidden: torch.Tensor, B: int, L: int, H: int,
-              hd: int, cos: torch.Tensor, sin: torch.Tensor, position_ids: Optional[torch.Tensor] = None):
-    """eagle/llama2.py:511-579 for N = B*L rows, causal, no cache.  Returns (predict [N,D], saved)."""
-    x0 = ops.embed_concat(emb, ids, hidden)                       # cat(embed(ids), hidden)      :515,:537-542
+              hd: int, cos: torch.Tensor, sin: torch.Tensor, position_ids: Optional[torch.Tensor] = None,
+              x0: Optional[torch.Tensor] = None):
+    """eagle/llama2.py:511-579 for N = B*L rows, causal, no cache.  Returns (predict [N,D], saved).
+    x0 [N, 2D]: cat(embed(ids), hidden) already built (the fused input path, data.make_eagle_draft_input)."""
+    if x0 is None:
+        x0 = ops.embed_concat(emb, ids, hidden)                   # cat(embed(ids), hidden)      :515,:537-542
     x = ops.gemm_nt(x0, W.fc_w, bias=W.fc_b)                      # fc                           :542
     qkv = ops.gemm_nt(x, W.wqkv)                                  # q|k|v projections            :222-224
     ops.rope_qk_(qkv, cos, sin, L, 2 * H, hd, position_ids=position_ids)        # :228-233
@@ -447,15 +450,21 @@ class EagleTrainer:
         works = []
         last = len(micro_batches) - 1
         for i, mb in enumerate(micro_batches):
-            hs = mb["hidden_states"]
-            B, L, D = hs.shape
+            x0 = mb.get("x0")                                               # fused input path: the fc input is already built
+            B, L = mb["loss_mask"].shape
+            D = model.config.hidden_size
             cos, sin = model._rope_tables(max(L, model.config.max_position_embeddings), dev)
-            if hs.dtype != BF16 or mb["target"].dtype != BF16:
+            if mb["target"].dtype != BF16 or (x0 is None and mb["hidden_states"].dtype != BF16):
                 raise TypeError("EagleTrainer.step: hidden_states and target must be bf16")
-            ids = mb["input_ids"].reshape(-1).to(torch.int64).contiguous()
             tgt = mb["target"].reshape(B * L, D).contiguous()
-            predict, saved = draft_fwd(W, model.embed_tokens.weight.detach(), ids, hs.reshape(B * L, D).contiguous(), B, L, H, hd,
-                                       cos, sin)
+            if x0 is not None:
+                if x0.dtype != BF16 or tuple(x0.shape) != (B * L, 2 * D) or not x0.is_contiguous():
+                    raise ValueError("EagleTrainer.step: x0 must be a contiguous bf16 [B*L, 2D] tensor")
+                predict, saved = draft_fwd(W, None, None, None, B, L, H, hd, cos, sin, x0=x0)
+            else:
+                ids = mb["input_ids"].reshape(-1).to(torch.int64).contiguous()
+                predict, saved = draft_fwd(W, model.embed_tokens.weight.detach(), ids,
+                                           mb["hidden_states"].reshape(B * L, D).contiguous(), B, L, H, hd, cos, sin)
             if self.sharded_loss is not None:
                 sums, dpred = self.sharded_loss.fwd_bwd(predict, tgt, masks[i], self.v_w, self.p_w, scale)
             else:

@@ -142,6 +142,11 @@ int64_t eagle_topk_workspace_bytes(int rows, int V, int k);
 int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V, int k,
                      int64_t* out_idx, void* out_val, void* workspace, const int64_t* block_index,
                      int64_t block_rows, eagle_stream_t stream);
+/* The same top-k written straight into a batched table: logits row r = b*group + j (request b, node j of the step) goes to
+ * out_idx / out_val + b*group_stride + j*k (elements) -- the flat top-k table [B, R, k] of the expansion loop (SURVEY.md
+ * a20) without a copy pass per step.  rows % group == 0, group_stride >= group*k. */
+int eagle_topk_vocab_grouped(const void* logits, int64_t ld, int dtype, int rows, int V, int k, int64_t* out_idx,
+                             void* out_val, void* workspace, int group, int64_t group_stride, eagle_stream_t stream);
 /* bf16 logits: the same top-k plus lse_out[rows] = fp32 log-sum-exp of every row out of the same pass over the logits
  * (stage 1 leaves a (max, sum-exp) pair per 1024-logit chunk, stage 2 merges them beside its final select) -- what
  * the dynamic tree's cumulative scores need (candidate probability = exp(logit - lse)) without a
@@ -220,7 +225,8 @@ int eagle_gather_accepted_bf16(const void* src, int n_nodes, int D, const int64_
 /* Dynamic draft tree (EAGLE-2 as SGLang serves it; benchmark/benchmark.py:48-56 passes
  * speculative_num_steps / speculative_eagle_topk / speculative_num_draft_tokens to sglang.Engine --
  * the algorithm itself is not in the reference; spec frozen in DESIGN.md 6b, oracle/dyn_tree.py).
- * Batch 1.  k = candidates per node (<= 16), S = steps, T = verified nodes incl. the root (<= 64),
+ * B independent requests per launch: every per-request array below is [B][...] contiguous (the shapes given are one
+ * request's).  k = candidates per node (<= 16), S = steps, T = verified nodes incl. the root (<= 64),
  * pool = k + (S-1) k^2 candidates (<= 1024) in production order; score = product of softmax
  * probabilities along the path; order = score descending, pool index ascending. */
 /* lse[r] = log sum_v exp(logits[r][v]) (fp32): the softmax normaliser of the draft head's top-k. */
@@ -228,28 +234,28 @@ int eagle_row_lse_bf16(const void* logits, int64_t ld, int rows, int V, float* l
 /* One expansion step: vals/ids [R,k] = top-k of the R = (step ? k : 1) rows just computed, lse [R].
  * Appends the R*k candidates to the pool (token, score, parent pool index) and, unless `last`, makes
  * the k best the next frontier: ftok [k], fscore_out [k], fpool_out [k], parent_row [k] (row of the
- * previous forward whose hidden state each takes; step 0: *root_row) and mask_out [k, (step+1) k] =
+ * previous BATCHED forward whose hidden state each takes: b*k + j; step 0: root_row[b]) and mask_out [k, (step+1) k] =
  * parent's row of mask_in [k, step k] | own column (select_top_k_tokens of SGLang's EAGLE worker). */
 int eagle_dyn_step(int step, int k, int last, const void* vals, const int64_t* ids, const float* lse,
                    const float* fscore_in, const int32_t* fpool_in, const uint8_t* mask_in,
                    const int64_t* root_row, int64_t* pool_tok, float* pool_score, int32_t* pool_parent,
                    int64_t* ftok, float* fscore_out, int32_t* fpool_out, int64_t* parent_row,
-                   uint8_t* mask_out, eagle_stream_t stream);
+                   uint8_t* mask_out, int S, int B, eagle_stream_t stream);
 /* The T-1 best pool entries, in pool order, become tree nodes 1..T-1 (organize_draft_results):
  * tree_tok [T] (node 0 = *root_token), tree_parent [T] int32 (root -1), tree_pos [T] (depth),
  * tree_mask [T,T] uint8 (self, root, ancestors), sel [T-1] (pool index of node n+1). */
 int eagle_dyn_finalize(int k, int S, int T, const int64_t* pool_tok, const float* pool_score,
                        const int32_t* pool_parent, const int64_t* root_token, int64_t* tree_tok,
                        int32_t* tree_parent, int64_t* tree_pos, uint8_t* tree_mask, int32_t* sel,
-                       eagle_stream_t stream);
+                       int B, eagle_stream_t stream);
 /* Greedy acceptance by walking the tree along target_argmax [T]; path [W] (node ids, -1 padded) doubles
  * as the one-row `retrieve` table of eagle_kv_compact_bf16 / eagle_gather_accepted_bf16 with
- * result = {0, accept_length, next_token, *prev_len + accept_length + 1}; next_ids / n_acc / last_idx /
- * len_cur / len_nxt / cursor as eagle_greedy_accept. */
+ * result = {0, accept_length, next_token, prev_len[b] + accept_length + 1}; next_ids / n_acc / last_idx (= b*W +
+ * accept_length) / len_cur / len_nxt / cursor (shared by the batch) as eagle_greedy_accept. */
 int eagle_dyn_accept(int T, int W, const int64_t* tree_tok, const int32_t* tree_parent,
                      const int64_t* target_argmax, const int32_t* prev_len, int64_t* path, int64_t* result,
                      int64_t* next_ids, int32_t* n_acc, int64_t* last_idx, int32_t* len_cur, int32_t* len_nxt,
-                     int64_t* cursor, eagle_stream_t stream);
+                     int64_t* cursor, int B, eagle_stream_t stream);
 
 /* Fused soft-label CE + smooth-L1 + agreement at the logits level.
  * Replaces eagle/train.py:108-123 (== eagle/train_tp.py:90-105).
@@ -316,9 +322,25 @@ int eagle_add_f32_bf16(const float* a, const void* b, void* out, int64_t n, eagl
 int eagle_make_eagle_input_bf16(const void* hidden, const void* noise, const int64_t* ids, void* hidden_out,
                                 void* target, int64_t* ids_out, int B, int L, int D, eagle_stream_t stream);
 
+/* _make_eagle_input (eagle/train.py:256-275) fused with the draft head's embedding gather + concat (eagle/llama2.py:515,
+ * :537-542): ONE pass over the verifier's last hidden state [B, L, D] (strides ldh_b / ldh_l elements, so a
+ * [:, :max_model_len] slice needs no copy) and the unshifted ids [B, >= L] (row stride ldi).
+ *   noise   = bf16(low + (high - low) * u), u ~ U[0,1) from Philox4x32-10 (counter = element index / 4, stream `offset`;
+ *             key = `seed`): drawn on the fly, never stored (noise_out [B*L, D], may be NULL, returns it for tests);
+ *             high == low: no noise.  The reference draws it in the hidden state's dtype and adds it in that dtype (:272-275).
+ *   x0      [B*L, 2D] = cat(embed_tokens[ids shifted left, trailing 0], hidden + noise): the input of the fc GEMM
+ *   target  [B*L, D]: target[:, :-1] = (hidden + noise)[:, 1:], last row of every sequence 0 (the target is noisy too)
+ *   ids_out [B*L] (may be NULL) = ids shifted left with trailing 0 (:266-268). */
+int eagle_input_embed_concat_bf16(const void* hidden, int64_t ldh_b, int64_t ldh_l, const int64_t* ids, int64_t ldi,
+                                  const void* emb, int V, float low, float high, uint64_t seed, uint64_t offset,
+                                  void* x0, void* target, int64_t* ids_out, void* noise_out, int B, int L, int D,
+                                  eagle_stream_t stream);
+
 /* ---- diagnostics (no counterpart in the reference): kernel-family overrides for A/B measurements and for the tests
  * that run every selectable path; process-wide, not for production hosts. ---- */
-/* eagle_gemm_nt_bf16: 0 = always the 128x128 kernel, 1 = the 256x256 kernel wherever legal, 2 = by shape (default). */
+/* eagle_gemm_nt_bf16: 0 = always the 128x128 kernel, 1 = the 256x256 kernel wherever legal, 2 = by shape (default);
+ * 0x100 | cfg: configuration of the decode-batch row kernels (<= 192 rows, N >= 8192): cfg 0 = by shape, 0x23 / 0x24 /
+ * 0x43 / 0x83 / 0x93 = (rows / 16) << 4 | LDS stages (0x93: 128 x 256 tiles on 8 waves), 0xfff = never. */
 void eagle_debug_set_gemm8(int mode);
 /* eagle_gemm_skinny_bf16 at <= 16 rows: 0 = tile kernel, 1 = streaming kernel, 2 = register-resident-x kernel where
  * K = 4096 (streaming otherwise), 3 = by shape (default); blocks_per_cu / min_rows > 0 override the streaming

@@ -21,6 +21,14 @@ def dev():
     return torch.device("cuda:0")
 
 
+def close(a, b, rtol=1e-2, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    tol = 2e-2 * float(b.abs().mean()) + float(b.abs().max()) / 256.0 + rtol * b.abs()
+    err = (a - b).abs()
+    bad = int((err > tol).sum())
+    assert bad <= 1e-3 * a.numel() and float((err / tol).max()) < 3.0, f"{what}: {bad}/{a.numel()} outside tol, max err {float(err.max()):.4g}"
+
+
 def _model(dims, w):
     from eagle_amd.config import DraftConfig
     from eagle_amd.llama2 import Llama2Model
@@ -277,3 +285,44 @@ def test_single_token_prompt_and_batch_of_one_ragged():
     assert torch.equal(ia, ib) and torch.equal(va, vb) and a.stable_len.tolist() == [1] == b.stable_len.tolist()
     a.check_errors()
     b.check_errors()
+
+
+@pytest.mark.parametrize("M,HK,use_tree", [(1, 32, False), (4, 32, True), (6, 32, False), (8, 8, True), (16, 32, False)])
+def test_wide_batch_attention_matches_the_per_request_kernel(M, HK, use_tree):
+    """The wide-batch attention (RoPE/append pre-pass + 512-key workgroups with P.V on MFMA, chosen when B*H >= 256)
+    against the 64-key split kernel run request by request (B*H < 256), which the oracle fixtures pin: same cache
+    contents bit for bit, outputs within the bf16 tolerance (the wide kernel rounds the probabilities to bf16 for the
+    MFMA, as the reference does; the split kernel keeps them fp32).  Ragged lengths incl. empty pasts and > 512 keys."""
+    from eagle_amd import ops
+    d = dev()
+    B, H, hd, cap = 9, 32, 128, 1024
+    g = torch.Generator().manual_seed(M * 10 + HK)
+    past = torch.tensor([0, 5, 63, 64, 300, 511, 512, 700, 37], dtype=torch.int32)
+    qkv = (torch.randn(B * M, (H + 2 * HK) * hd, generator=g) * 0.8).to(BF).to(d)
+    kc = torch.randn(B, HK, cap, hd, generator=g).to(BF).to(d)
+    vc = torch.randn(B, HK, cap, hd, generator=g).to(BF).to(d)
+    cos, sin = ops.rope_tables(hd, 2048, device=d)
+    tmask = None
+    if use_tree:
+        tm = (torch.rand(M, M, generator=g) < 0.5).to(torch.uint8)
+        tm[torch.arange(M), torch.arange(M)] = 1
+        tmask = tm.to(d).contiguous()
+    max_kv = 1024
+    err = torch.zeros(1, dtype=torch.int32, device=d)
+
+    def run(Bn, qkv_, kc_, vc_, past_):
+        out = torch.zeros((Bn * M, H * hd), dtype=BF, device=d)
+        ws = torch.empty(ops.query("eagle_attn_decode_workspace_bytes", Bn, H, max_kv), dtype=torch.uint8, device=d)
+        ops.tree_attention(qkv_, None, cos, sin, kc_, vc_, past_, 0, tmask, None, out, ws, err, Bn, M, H, HK, hd, max_kv, True, M, 0,
+                           pos_off=0, pos_stride=0 if use_tree else 1)
+        return out
+    kw, vw = kc.clone(), vc.clone()
+    wide = run(B, qkv, kw, vw, past.to(d))
+    ref = torch.empty_like(wide)
+    ks, vs = kc.clone(), vc.clone()
+    for b in range(B):
+        ref[b * M:(b + 1) * M] = run(1, qkv[b * M:(b + 1) * M], ks[b:b + 1], vs[b:b + 1], past[b:b + 1].to(d))
+    assert int(err.item()) == 0
+    assert torch.equal(kw, ks) and torch.equal(vw, vs), "appended K/V rows differ"
+    for b in range(B):
+        close(wide[b * M:(b + 1) * M], ref[b * M:(b + 1) * M], what=f"request {b} (past {int(past[b])})")

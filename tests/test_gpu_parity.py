@@ -575,7 +575,9 @@ def test_drafter_cycle_index_logic_matches_oracle_loop_on_hip_logits(expand):
 
 # ------------------------------------------------------------------ large-M MFMA GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 130, 192), (2048, 4096, 4096), (300, 4096, 8192),
-                                   (64, 1000, 128), (1024, 22016, 4096)])
+                                   (64, 1000, 128), (1024, 22016, 4096),
+                                   # decode batches against a tall matrix: the deep-pipelined row kernel (<= 32 rows, N >= 8192)
+                                   (32, 8192, 256), (7, 9000, 4096), (32, 151936, 4096)])
 def test_gemm_nt(M, N, K):
     from eagle_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
@@ -642,6 +644,30 @@ def test_gemm_nt_256_tile_kernel(M, N, K):
         assert torch.equal(y128, y256)        # same K order and MFMA shape: identical fp32 sums
     finally:
         setm(2)
+
+
+@pytest.mark.parametrize("cfg", [0x123, 0x124, 0x143, 0x183, 0x193])
+@pytest.mark.parametrize("M,N,K", [(32, 8192, 256), (100, 8300, 1024), (192, 16384, 512), (1, 8192, 4096)])
+def test_gemm_nt_row_kernel_configurations(cfg, M, N, K):
+    """Every selectable configuration of the decode-batch row kernels (LDS-DMA stages in flight across the barrier of a
+    K step) against the 128x128 kernel: same MFMA shape and K order, so bit-identical outputs; ragged M / N, bias + res."""
+    from eagle_amd import _hip, ops
+    setm = _hip.lib().eagle_debug_set_gemm8
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(BF).to(dev())
+    Bm = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(dev())
+    bias = torch.randn(N, generator=g).to(BF).to(dev())
+    res = torch.randn(M, N, generator=g).to(BF).to(dev())
+    try:
+        setm(0x1fff)
+        ref, ref2 = ops.gemm_nt(A, Bm), ops.gemm_nt(A, Bm, bias=bias, res=res)
+        setm(0x100 | (cfg & 0xff))
+        for _ in range(2):
+            assert torch.equal(ops.gemm_nt(A, Bm), ref)
+        assert torch.equal(ops.gemm_nt(A, Bm, bias=bias, res=res), ref2)
+    finally:
+        setm(0x100)
+    close(ref, A.float().cpu() @ Bm.float().cpu().t(), what="row kernel vs fp32")
 
 
 @pytest.mark.parametrize("M,N,K,S", [(256, 256, 1024, 4), (300, 130, 64 * 37, 5), (2048, 512, 8192, 4), (64, 64, 128, 8),

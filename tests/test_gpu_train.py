@@ -372,3 +372,89 @@ def test_trainer_over_a_real_rccl_group_of_one_rank():
         assert torch.allclose(s1, s0, rtol=1e-5, atol=1e-5) and rel_l2(d1, d0) < 1e-2
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ fused input path
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al., SC'11) on uint32 numpy arrays: ctr [n, 4], key (k0, k1) -> [n, 4]."""
+    import numpy as np
+    c = [ctr[:, i].astype(np.uint64) for i in range(4)]
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, W0, W1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[1] ^ k0) & MASK
+        n2 = ((p0 >> np.uint64(32)) ^ c[3] ^ k1) & MASK
+        c = [n0, p1 & MASK, n2, p0 & MASK]
+        k0, k1 = (k0 + W0) & MASK, (k1 + W1) & MASK
+    return np.stack(c, axis=1).astype(np.uint32)
+
+
+def test_philox_known_answer():
+    """Random123's published known-answer vectors for philox4x32-10: the numpy restatement the device kernel is checked
+    against is itself pinned."""
+    import numpy as np
+    out = philox4x32_10(np.zeros((1, 4), dtype=np.uint32), (0, 0))[0]
+    assert [hex(int(v)) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    out = philox4x32_10(np.full((1, 4), 0xFFFFFFFF, dtype=np.uint32), (0xFFFFFFFF, 0xFFFFFFFF))[0]
+    assert [hex(int(v)) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+def test_fused_eagle_input_matches_oracle_and_philox():
+    """eagle_input_embed_concat_bf16 = _make_eagle_input (train.py:256-275) + embedding gather / concat (llama2.py:515,
+    :537-542) in one pass: the noise is Philox4x32-10 bit for bit, and GIVEN that noise x0 / target / ids equal the
+    oracle's make_eagle_input + cat exactly; a [:, :max_len] slice of a longer hidden state needs no copy."""
+    import numpy as np
+    from eagle_amd import data
+    B, Lfull, D, V, max_len = 3, 11, 64, 50, 9
+    g = torch.Generator().manual_seed(3)
+    emb = torch.randn(V, D, generator=g).to(BF)
+    hid = torch.randn(B, Lfull, D, generator=g).to(BF)
+    ids = torch.randint(0, V, (B, Lfull), generator=g)
+    mask = (torch.rand(B, Lfull, generator=g) < 0.6).long()
+    low, high, seed, offset = -0.1, 0.1, 0x1234567887654321, 7
+    out = data.make_eagle_draft_input({"input_ids": ids, "loss_mask": mask}, hid.to(DEV), emb.to(DEV), max_len, low, high, seed=seed,
+                                      offset=offset, want_noise=True)
+    n = B * max_len * D
+    e4 = np.arange(n // 4, dtype=np.uint64)
+    ctr = np.stack([e4 & 0xFFFFFFFF, e4 >> 32, np.full_like(e4, offset & 0xFFFFFFFF), np.full_like(e4, offset >> 32)], axis=1).astype(np.uint32)
+    r = philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32)).reshape(-1)
+    u = torch.from_numpy((r >> 8).astype(np.float32)) * 2.0 ** -24
+    noise = torch.addcmul(torch.tensor(low), u, torch.tensor(high - low))         # fma in fp32 ...
+    noise_ref = noise.to(BF).view(B, max_len, D)                                       # ... rounded to the hidden dtype
+    got_noise = out["noise"].cpu()
+    assert float((got_noise.float() - noise_ref.float()).abs().max()) <= 2.0 ** -10    # one bf16 ulp at 0.1 (fma vs mul+add rounding)
+    assert float(got_noise.float().min()) >= low - 1e-3 and float(got_noise.float().max()) <= high + 1e-3
+    assert abs(float(got_noise.float().mean())) < 2e-3 and abs(float(got_noise.float().std()) - 0.2 / 12 ** 0.5) < 2e-3
+    ref = ol.make_eagle_input(ids, mask, hid, max_len, noise=got_noise)                # the oracle, given the device's noise
+    assert torch.equal(out["input_ids"].cpu(), ref["input_ids"]) and torch.equal(out["loss_mask"].cpu(), ref["loss_mask"])
+    assert torch.equal(out["target"].cpu(), ref["target"])
+    assert torch.equal(out["hidden_states"].cpu(), ref["hidden_states"])
+    x0_ref = torch.cat((emb[ref["input_ids"]], ref["hidden_states"]), dim=-1).view(B * max_len, 2 * D)
+    assert torch.equal(out["x0"].cpu(), x0_ref)
+    # no noise: high == low == 0 -> plain shift
+    out0 = data.make_eagle_draft_input({"input_ids": ids, "loss_mask": mask}, hid.to(DEV), emb.to(DEV), max_len)
+    assert torch.equal(out0["hidden_states"].cpu(), hid[:, :max_len])
+    # a different offset draws a different stream
+    out2 = data.make_eagle_draft_input({"input_ids": ids, "loss_mask": mask}, hid.to(DEV), emb.to(DEV), max_len, low, high, seed=seed, offset=8,
+                                       want_noise=True)
+    assert not torch.equal(out2["noise"], out["noise"])
+
+
+def test_trainer_step_from_the_fused_input_equals_the_two_pass_input():
+    from eagle_amd import data
+    from eagle_amd.train import EagleTrainer
+    res = []
+    mb = make_batch(41, 2, 64)
+    for fused in (False, True):
+        model, wb, lm_head = make_model(seed=13)
+        tr = EagleTrainer(model, lm_head.to(DEV), lr=1e-3, mode="dp")
+        raw = {"input_ids": mb["input_ids"], "loss_mask": mb["loss_mask"]}
+        if fused:
+            d = data.make_eagle_draft_input(raw, mb["hidden_states"].to(DEV), model.embed_tokens.weight.detach(), 64)
+            step_in = {"x0": d["x0"], "target": d["target"], "loss_mask": d["loss_mask"]}
+        else:
+            step_in = data.make_eagle_batch(raw, mb["hidden_states"].to(DEV), 64)
+        out = tr.step([step_in])
+        res.append((tr.flat.clone(), out["sums"].clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
