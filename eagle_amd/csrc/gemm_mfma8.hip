@@ -50,6 +50,7 @@ struct Gemm8Args {
   int ksplit;          // > 1: grid = tiles x ksplit, slice s multiplies K tiles [s*kchunk, ...) into partial[s]
   int kchunk;          // K tiles per slice
   float* partial;      // [ksplit][M][N] fp32 (split-K only)
+  int tn;              // operands stored K-major: A [K, M] (row stride lda), B [K, N] (row stride ldb)
 };
 
 // Operand staging by buffer_load ... lds: the row/chunk part of every lane's source address never
@@ -80,6 +81,47 @@ __device__ __forceinline__ G8Src g8_src(const bf16_t* X, int64_t ld, int nrows, 
     }
   return s;
 }
+// K-major operands ("TN": C = A^T . B with A [K, M], B [K, N] -- the weight-gradient GEMMs dW = dY^T . X read dY and X as
+// they lie in memory, no transpose pass): a half-tile is [64 k rows][128 columns] = 64 rows of 256 B, staged row-major with
+// the 16-byte chunk swizzle of the training attention's V tile (attn_train.hip a2_off); the MFMA fragments (8 consecutive k
+// of one column per lane) come out of it through transposing LDS reads, ds_read_b64_tr_b16, two per fragment.
+__device__ __forceinline__ int g8_tn_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ G8Src g8_src_tn(const bf16_t* X, int64_t ld, int c0, int K, int tid) {
+  G8Src s;
+  const bf16_t* base = X + c0;
+  const uint64_t bytes = ((uint64_t)(K - 1) * (uint64_t)ld + 256ull) * 2ull;
+  s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes), 0x00020000);
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int L = i * G8_THREADS + tid;      // 16-byte slot in the [64][16] image
+      const int row = L >> 4, slot = L & 15;
+      const int chunk = slot ^ (((row & 3) << 2) | ((row >> 2) & 3));
+      s.voff[h][i] = (uint32_t)(((uint64_t)row * (uint64_t)ld + (uint64_t)(h * 128 + chunk * 8)) * 2ull);
+    }
+  return s;
+}
+__device__ __forceinline__ void g8_stage_tn(const G8Src& s, int h, int kt, uint32_t ktile_bytes, bf16_t* lds, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    bf16_t* d = lds + (i * G8_THREADS + wave * 64) * 8;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(s.rsrc, (__attribute__((address_space(3))) void*)d, 16, s.voff[h][i],
+                                             kt * ktile_bytes, 0, 0);
+  }
+}
+typedef __attribute__((ext_vector_type(4))) short g8_s4;
+__device__ __forceinline__ bf16x8 g8_tn_frag(const bf16_t* img, int tile, int s, int g, int tq, int tp) {
+  const char* b = reinterpret_cast<const char*>(img);
+  const int r0 = 32 * s + 4 * g + tq;
+  const g8_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) g8_s4*)(b + g8_tn_off(r0, 2 * tile + (tp >> 1)) + 8 * (tp & 1)));
+  const g8_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) g8_s4*)(b + g8_tn_off(r0 + 16, 2 * tile + (tp >> 1)) + 8 * (tp & 1)));
+  union { struct { g8_s4 a, b; } q; bf16x8 v; } u;
+  u.q.a = lo; u.q.b = hi;
+  return u.v;
+}
+
 // half-tile `h` at K tile kt -> lds (wave-uniform LDS base in M0; the hardware adds lane*16)
 __device__ __forceinline__ void g8_stage(const G8Src& s, int h, int kt, bf16_t* lds, int tid) {
   const int wave = tid >> 6;
@@ -91,7 +133,7 @@ __device__ __forceinline__ void g8_stage(const G8Src& s, int h, int kt, bf16_t* 
   }
 }
 
-template <bool PINGPONG, int DBG = 0>
+template <bool PINGPONG, int DBG = 0, bool TN = false>
 __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   // ONE shared array (a second LDS object makes hipcc drain the DMA before every ds_read):
   // [buffer 2][A0, A1, B0, B1][128 x 64]  = 128 KB
@@ -127,9 +169,16 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   const int nk = min(p.kchunk, nk_all - kt0);       // K tiles of this slice (>= 1: launcher)
   auto kt_of = [&](int t) { return (DBG & 8) ? kt0 + (t & 1) : kt0 + (t < nk ? t : nk - 1); };
   auto hbuf = [&](int buf, int which) { return lds + (buf * 4 + which) * G8_HALF; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
-  const G8Src srcA = g8_src(p.A, p.lda, p.M, m0, p.K, tid), srcB = g8_src(p.B, p.ldb, p.N, n0, p.K, tid);
-  auto stage_a = [&](int h, int t) { g8_stage(srcA, h, kt_of(t), hbuf(t & 1, h), tid); };
-  auto stage_b = [&](int h, int t) { g8_stage(srcB, h, kt_of(t), hbuf(t & 1, 2 + h), tid); };
+  const G8Src srcA = TN ? g8_src_tn(p.A, p.lda, m0, p.K, tid) : g8_src(p.A, p.lda, p.M, m0, p.K, tid);
+  const G8Src srcB = TN ? g8_src_tn(p.B, p.ldb, n0, p.K, tid) : g8_src(p.B, p.ldb, p.N, n0, p.K, tid);
+  const uint32_t ktA = (uint32_t)(p.lda * (G8_BK * 2)), ktB = (uint32_t)(p.ldb * (G8_BK * 2));   // TN: bytes per K tile of rows
+  auto stage_a = [&](int h, int t) {
+    if (TN) g8_stage_tn(srcA, h, kt_of(t), ktA, hbuf(t & 1, h), tid); else g8_stage(srcA, h, kt_of(t), hbuf(t & 1, h), tid);
+  };
+  auto stage_b = [&](int h, int t) {
+    if (TN) g8_stage_tn(srcB, h, kt_of(t), ktB, hbuf(t & 1, 2 + h), tid); else g8_stage(srcB, h, kt_of(t), hbuf(t & 1, 2 + h), tid);
+  };
+  const int tq = (lane & 15) >> 2, tp = lane & 3;        // transposing-read lane geometry (TN)
 
   // prologue: tile 0 complete, B halves of tile 1 in flight
   stage_b(0, 0); stage_b(1, 0); stage_a(0, 0); stage_a(1, 0);
@@ -145,8 +194,10 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
     for (int i = 0; i < 4; ++i) {
       const int row = a_row0 + mh * 64 + i * 16;
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        af[i][s] = *reinterpret_cast<const bf16x8*>(la + row * G8_BK + (((4 * s + g) ^ (row & 7)) << 3));
+      for (int s = 0; s < 2; ++s) {
+        if (TN) af[i][s] = g8_tn_frag(la, mh * 4 + i, s, g, tq, tp);
+        else af[i][s] = *reinterpret_cast<const bf16x8*>(la + row * G8_BK + (((4 * s + g) ^ (row & 7)) << 3));
+      }
     }
   };
   auto read_b = [&](const bf16_t* lb, int nh, bf16x8 (&bf)[2][2]) {
@@ -154,8 +205,10 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
     for (int j = 0; j < 2; ++j) {
       const int row = b_row0 + nh * 32 + j * 16;
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
-        bf[j][s] = *reinterpret_cast<const bf16x8*>(lb + row * G8_BK + (((4 * s + g) ^ (row & 7)) << 3));
+      for (int s = 0; s < 2; ++s) {
+        if (TN) bf[j][s] = g8_tn_frag(lb, (wc & 1) * 4 + nh * 2 + j, s, g, tq, tp);
+        else bf[j][s] = *reinterpret_cast<const bf16x8*>(lb + row * G8_BK + (((4 * s + g) ^ (row & 7)) << 3));
+      }
     }
   };
 
@@ -431,10 +484,33 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
   a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = (N + G8_BN - 1) / G8_BN;
   a.gm = a.tiles_m < 8 ? a.tiles_m : 8;             // row tiles per group of the grouped tile order
+  a.tn = 0;
   hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
   int rc = eagle_check_launch();
   if (rc || a.ksplit == 1) return rc;
   const int64_t q4 = (int64_t)M * ((N + 3) / 4);
   hipLaunchKernelGGL(gemm8_reduce_kernel, dim3((unsigned)((q4 + 255) / 256)), dim3(256), 0, stream, a);
+  return eagle_check_launch();
+}
+
+// C[M,N] (+)= A^T . B with K-major operands: A [K, M] (row stride lda), B [K, N] (row stride ldb) -- the weight-gradient GEMMs
+// behind loss.backward() (eagle/train.py:126): dW[out, in] = dY[tokens, out]^T . X[tokens, in], both read as they lie in memory.
+// M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128; lda / ldb % 8 == 0; 16-byte aligned bases.
+extern "C" int eagle_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                                  int out_f32, int accumulate, hipStream_t stream) {
+  if (!A || !B || !C) return EAGLE_ERR_ARG;
+  if (M < 256 || N < 256 || (M & 255) || (N & 255) || K < 2 * G8_BK || (K % G8_BK)) return EAGLE_ERR_SHAPE;
+  if ((lda & 7) || (ldb & 7) || lda < M || ldb < N || ldc < N) return EAGLE_ERR_SHAPE;
+  if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15)) return EAGLE_ERR_SHAPE;
+  if ((uint64_t)K * (uint64_t)(lda > ldb ? lda : ldb) * 2ull > 0xffffffffull) return EAGLE_ERR_SHAPE;   // 32-bit byte offsets over K
+  Gemm8Args a;
+  a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.bias = nullptr; a.res = nullptr; a.ldr = 0;
+  a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
+  a.tiles_m = M / G8_BM; a.tiles_n = N / G8_BN;
+  a.ksplit = 1; a.kchunk = K / G8_BK; a.partial = nullptr;
+  a.gm = a.tiles_m < 8 ? a.tiles_m : 8;
+  a.tn = 1;
+  hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, true>), dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
   return eagle_check_launch();
 }

@@ -109,6 +109,31 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_tn_ok(A: torch.Tensor, B: torch.Tensor) -> bool:
+    """Shapes eagle_gemm_tn_bf16 takes: A [K, M], B [K, N] row-major, M and N multiples of 256, K a multiple of 64."""
+    K, M = A.shape
+    N = B.shape[1]
+    return (B.shape[0] == K and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K >= 128 and A.stride(1) == 1 and B.stride(1) == 1
+            and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and K * max(A.stride(0), B.stride(0)) * 2 < 2 ** 32
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_tn(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, out_dtype=BF16, accumulate: bool = False) -> torch.Tensor:
+    """C[M,N] (+)= A^T @ B for K-major operands A [K, M], B [K, N] (weight gradients: no transpose pass)."""
+    _chk(A, "A"), _chk(B, "B")
+    K, M = A.shape
+    N = B.shape[1]
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate needs an output tensor")
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    if out.dtype not in (BF16, torch.float32) or out.stride(1) != 1 or tuple(out.shape) != (M, N):
+        raise TypeError("gemm_tn: C must be bf16 or fp32 [M, N], row-major")
+    call("eagle_gemm_tn_bf16", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0), M, N, K,
+         int(out.dtype == torch.float32), int(accumulate), stream())
+    return out
+
+
 def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 1) -> torch.Tensor:
     """out[C, R_pad] = x[R,C]^T (bf16); R_pad = R rounded up to ``pad_to``, the extra columns zero."""
     _chk(x, "x")

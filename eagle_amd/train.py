@@ -155,30 +155,35 @@ def draft_bwd(W: LayerWeights, saved, dout: torch.Tensor, B: int, L: int, H: int
     ready = on_ready or (lambda name: None)
     def T(t):                                                     # [rows, C] -> [C, rows padded to the GEMM's K step]
         return ops.transpose(t, pad_to=64)
+
+    def wgrad(dy, xin, out):
+        """out[out_f, in_f] (+)= dy[tokens, out_f]^T . xin[tokens, in_f].  Both operands are K-major as they lie in memory: the
+        TN kernel (transposing LDS fragment reads) takes them directly; other shapes go through two transposes."""
+        if ops.gemm_tn_ok(dy, xin):
+            ops.gemm_tn(dy, xin, out=out, accumulate=acc)
+        else:
+            ops.gemm_nt(T(dy), T(xin), out=out, accumulate=acc)
     # down_proj: out = act . Wdown^T + h1
     d_act = ops.gemm_nt(dout, tc.get("wdown", W.wdown))
-    doutT = T(dout)
-    ops.gemm_nt(doutT, T(act), out=sink.wdown, accumulate=acc)
+    wgrad(dout, act, sink.wdown)
     ready("wdown")
     dgu = ops.silu_mul_bwd(gu, d_act)
     del d_act
     dn = ops.gemm_nt(dgu, tc.get("wgu", W.wgu))
-    ops.gemm_nt(T(dgu), T(n), out=sink.wgu, accumulate=acc)
+    wgrad(dgu, n, sink.wgu)
     ready("wgu")
     del dgu
     dh1, _ = ops.rmsnorm_bwd(dn, h1, W.wn, rstd, res=dout, dw=sink.wn, accumulate_dw=acc)   # + residual branch
     ready("wn")
     d_attn = ops.gemm_nt(dh1, tc.get("wo", W.wo))
-    dh1T = T(dh1)
-    ops.gemm_nt(dh1T, T(attn), out=sink.wo, accumulate=acc)
+    wgrad(dh1, attn, sink.wo)
     ready("wo")
     dqkv = ops.attn_train_bwd(qkv, attn, d_attn, lse, B, L, H, hd)
     ops.rope_qk_(dqkv, cos, sin, L, 2 * H, hd, position_ids=position_ids, inverse=True)
     dx = ops.gemm_nt(dqkv, tc.get("wqkv", W.wqkv), res=dh1)       # + residual branch of :385
-    ops.gemm_nt(T(dqkv), T(x), out=sink.wqkv, accumulate=acc)
+    wgrad(dqkv, x, sink.wqkv)
     ready("wqkv")
-    dxT = T(dx)
-    ops.gemm_nt(dxT, T(x0), out=sink.fc_w, accumulate=acc)
+    wgrad(dx, x0, sink.fc_w)
     if sink.fc_b is not None:
         ops.colsum(dx, sink.fc_b, accumulate=acc)
     ready("fc")

@@ -65,6 +65,13 @@ int64_t eagle_gemm_nt_splitk_workspace_bytes(int M, int N, int ksplit);
 int eagle_gemm_nt_splitk_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                               const void* bias, const void* res, int64_t ldr, int M, int N, int K, int out_f32,
                               int accumulate, int ksplit, void* workspace, eagle_stream_t stream);
+/* C[M,N] (+)= A^T . B with K-MAJOR operands A [K, M] (row stride lda) and B [K, N] (row stride ldb), on the 256x256 kernel
+ * with transposing LDS fragment reads: the weight-gradient GEMMs behind loss.backward() (eagle/train.py:126),
+ * dW[out, in] = dY[tokens, out]^T . X[tokens, in], read dY and X as they lie in memory -- no eagle_transpose_bf16 pass.
+ * M % 256 == 0, N % 256 == 0, K % 64 == 0, K >= 128, K * max(lda, ldb) * 2 < 4 GiB; other shapes: EAGLE_ERR_SHAPE (the host
+ * then transposes and calls eagle_gemm_nt_bf16).  C bf16 (out_f32 = 0) or fp32; accumulate != 0: C += result. */
+int eagle_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                       int out_f32, int accumulate, eagle_stream_t stream);
 /* out[C,R_pad] = in[R,C]^T, bf16, columns [R, R_pad) zero-filled (R_pad < R: no padding): operand
  * preparation for the dgrad / wgrad GEMMs behind loss.backward() (eagle/train.py:126); the zero
  * padding lets a token count that is no multiple of 64 serve as the GEMM's K.  ldo >= R_pad. */

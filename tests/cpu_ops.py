@@ -30,6 +30,10 @@ def gemm_nt(A, B, bias=None, res=None, out=None, out_dtype=BF16, accumulate=Fals
     return out
 
 
+def gemm_tn_ok(A, B):
+    return False            # the CPU stand-ins take the transpose + NT route
+
+
 def transpose(x, out=None, pad_to=1):
     R, C = x.shape
     Rp = (R + pad_to - 1) // pad_to * pad_to
@@ -232,7 +236,7 @@ def install(monkeypatch_setattr=None):
     g = globals()
     for name in ("gemm_nt", "transpose", "embed_concat", "rope_qk_", "attn_train_fwd", "attn_train_bwd", "rmsnorm", "rmsnorm_bwd",
                  "silu_mul", "silu_mul_bwd", "colsum", "adamw_", "grad_clip_coef", "clip_value_", "scale_", "add_f32_bf16",
-                 "ce_partial", "ce_combine", "ce_smoothl1_bwd", "rope_tables", "require_device"):
+                 "ce_partial", "ce_combine", "ce_smoothl1_bwd", "rope_tables", "require_device", "gemm_tn_ok"):
         if monkeypatch_setattr is not None:
             monkeypatch_setattr(ops, name, g[name])
         else:

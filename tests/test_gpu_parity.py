@@ -692,6 +692,38 @@ def test_gemm_nt_split_k(M, N, K, S):
     close(yf, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="split-k fp32")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 4096), (4096, 12288, 2048), (256, 1024, 64 * 5)])
+def test_gemm_tn_k_major_operands(M, N, K):
+    """C (+)= A^T . B with A [K, M], B [K, N] as they lie in memory (the weight-gradient GEMMs, no transpose pass): against
+    fp32 torch, and against transposing both operands and running the NT 256x256 kernel (the transposing reads permute k
+    inside an MFMA's 32-deep step, so the fp32 sums differ in the last bits, not more)."""
+    from eagle_amd import _hip, ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(K, M, generator=g).to(BF).to(dev())
+    Bm = (torch.randn(K, N, generator=g) / K ** 0.5).to(BF).to(dev())
+    assert ops.gemm_tn_ok(A, Bm)
+    ref = A.float().cpu().t() @ Bm.float().cpu()
+    y = ops.gemm_tn(A, Bm)
+    close(y, ref, what="gemm_tn bf16")
+    close(ops.gemm_tn(A, Bm, out_dtype=torch.float32), ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="gemm_tn fp32")
+    acc = torch.randn(M, N, generator=g).to(BF).to(dev())
+    ya = ops.gemm_tn(A, Bm, out=acc.clone(), accumulate=True)
+    close(ya, acc.float().cpu() + ref, what="gemm_tn accumulate")
+    setm = _hip.lib().eagle_debug_set_gemm8
+    try:
+        setm(1)
+        y_nt = ops.gemm_nt(ops.transpose(A), ops.transpose(Bm))
+        ya_nt = ops.gemm_nt(ops.transpose(A), ops.transpose(Bm), out=acc.clone(), accumulate=True)
+    finally:
+        setm(2)
+    assert float((y.float() - y_nt.float()).abs().max()) <= 2.0 ** -7 * float(y_nt.float().abs().max())
+    assert float((ya.float() - ya_nt.float()).abs().max()) <= 2.0 ** -7 * float(ya_nt.float().abs().max())
+    # a column slice of a wider matrix (ld > M) and ragged shapes are rejected by the shape check, not mis-read
+    wide = torch.randn(K, M + 256, generator=g).to(BF).to(dev())
+    close(ops.gemm_tn(wide[:, 256:], Bm), wide[:, 256:].float().cpu().t() @ Bm.float().cpu(), what="gemm_tn strided A")
+    assert not ops.gemm_tn_ok(A[:, :100], Bm) and not ops.gemm_tn_ok(A[:100], Bm[:100])
+
+
 def test_transpose():
     from eagle_amd import ops
     g = torch.Generator().manual_seed(4)
