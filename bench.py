@@ -162,7 +162,7 @@ def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, pla
 
 
 def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
-    """Dominant kernel: gemm_skinny_keepx_kernel<2,0,4> = the lm_head weight stream (one launch per
+    """Dominant kernel: gemm_skinny_keepx_kernel<1,0,4> = the lm_head weight stream (one launch per
     draft-tree step).  Measured IN the cycle, not back to back: `cycles` eager draft/verify cycles
     with a HIP event pair (on the launch stream = torch's current stream) around every lm_head
     launch, so each launch starts behind the down-projection kernel as it does in the timed region
@@ -170,7 +170,7 @@ def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
     their ramp and drain).  Algorithmic bytes per launch = V*D*2 (weights) + M*D*2 (x) + M*V*2
     (logits), M = the step's row count; achieved = sum(bytes) / sum(durations).
     `traffic`: HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape
-    (profiles/r01_lm_head_pmc.json, collected with tools/gpu_profile.sh), else null."""
+    (profiles/r02_lm_head_pmc.json, collected with tools/gpu_profile.sh), else null."""
     from eagle_amd import ops
     W = drafter.lm_head
     V, D = W.shape
@@ -201,12 +201,14 @@ def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
     sec = sum(e0.elapsed_time(e1) for e0, e1, _ in marks) / 1e3
     nbytes = sum(V * D * 2 + m * D * 2 + m * V * 2 for _, _, m in marks)
     traffic = None
-    pj = os.path.join(ROOT, "profiles", "r01_lm_head_pmc.json")
-    if V == 32000 and os.path.exists(pj):
-        with open(pj) as f:
-            traffic = json.load(f).get("traffic_bytes_per_launch")
+    for name in ("r02_lm_head_pmc.json", "r01_lm_head_pmc.json"):      # newest PMC pass of this kernel and shape
+        pj = os.path.join(ROOT, "profiles", name)
+        if V == 32000 and os.path.exists(pj):
+            with open(pj) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
+            break
     n = len(marks)
-    return {"bound": "hbm", "kernel": "gemm_skinny_keepx_kernel<2,0,4> (lm_head weight stream, 1-8 rows, in-cycle)",
+    return {"bound": "hbm", "kernel": "gemm_skinny_keepx_kernel<1,0,4> (lm_head weight stream, 1-8 rows, in-cycle)",
             "achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": nbytes / n, "us_per_launch": sec / n * 1e6, "launches_timed": n,

@@ -1,6 +1,6 @@
 """Turn the two rocprofv3 --pmc passes of tools/gpu_profile.sh (FETCH_SIZE, WRITE_SIZE of
 tools/prof_lm_head.py) into profiles/<name>.json, the file bench.py's `roofline.traffic` reads.
-    python tools/pmc_to_json.py gpurun_out/prof_X profiles/r01_lm_head_pmc.json
+    python tools/pmc_to_json.py gpurun_out/prof_X profiles/r02_lm_head_pmc.json
 """
 import csv
 import glob
@@ -24,7 +24,7 @@ write = per_launch(root + "/pmc_write", "WRITE_SIZE")
 traffic = (sum(fetch) / len(fetch) * 2 + sum(write) / len(write)) * 1024
 alg = V * D * 2 + ROWS * D * 2 + ROWS * V * 2
 json.dump({
-    "kernel": "gemm_skinny_keepx_kernel<2,0,4> (lm_head, %d rows x %d x %d bf16)" % (ROWS, V, D),
+    "kernel": "gemm_skinny_keepx_kernel<1,0,4> (lm_head, %d rows x %d x %d bf16)" % (ROWS, V, D),
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 tools/prof_lm_head.py (separate passes)",
     "FETCH_SIZE_KB_per_launch": fetch,
     "WRITE_SIZE_KB_per_launch": write,

@@ -1,5 +1,5 @@
 """PMC target: N launches of the dominant decode kernel (the lm_head weight stream of bench.py's
-`roofline`: gemm_skinny_keepx_kernel<2,0,4>, 4 rows x 32000 x 4096 bf16) and nothing else of note, so that
+`roofline`: gemm_skinny_keepx_kernel<1,0,4>, 4 rows x 32000 x 4096 bf16) and nothing else of note, so that
 rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE rows of that kernel can be read per launch.
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/prof_lm_head.py
 """
