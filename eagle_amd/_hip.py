@@ -30,6 +30,8 @@ class HipKernelError(RuntimeError):
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, I, L, F, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
+    "eagle_gemm_rows_workspace_bytes": (L, [I, I, I, I]),
+    "eagle_gemm_rows_bf16": (I, [P, P, L, I, P, I, L, P, P, L, P, P, L, P, P, L, P, L, I, I, I, I, P, L, P]),
     "eagle_gemm_nt_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, P]),
     "eagle_gemm_nt_splitk_workspace_bytes": (L, [I, I, I]),
     "eagle_gemm_nt_splitk_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, P, P]),
@@ -79,6 +81,7 @@ SIGNATURES = {
     "eagle_input_embed_concat_bf16": (I, [P, L, L, P, L, P, I, F, F, ctypes.c_uint64, ctypes.c_uint64, P, P, P, P, I, I, I, P]),
     "eagle_debug_set_gemm8": (None, [I]),
     "eagle_debug_set_skinny_variant": (None, [I, I, I]),
+    "eagle_debug_set_rows": (None, [I, I, I]),
 }
 
 _lib = None

@@ -1,0 +1,423 @@
+// Weight-streaming GEMM for decode batches of 17..128 rows (batch-32 tree steps: 32 x {1,4} rows per forward).
+//
+//   out[M,N] = epilogue( x[M,K] . W[N,K]^T )        bf16 in, fp32 accumulate, same epilogues as gemm_skinny.hip
+//
+// Replaces the nn.Linear calls of eagle/llama2.py at draft time (fc :542, q/k/v/o_proj :222-224/:280, gate/up/down_proj
+// :317) and the frozen lm_head (eagle/train.py:215-228) when a batch of requests steps through the tree together.  At that
+// size the op is still a weight stream (a 128-row step multiplies 8 MFMAs per KB of weights: a third of the MFMA rate the
+// HBM stream could feed), so the two operands travel by different roads:
+//   * W is the MFMA A operand and is used by ONE wave only: HBM -> VGPR directly (non-temporal 16-B loads, S register
+//     stages of one 128-wide K super-step each), as in gemm_skinny_keepx_kernel -- no LDS round trip;
+//   * x is shared by the four consumer waves and re-read by every column tile: it goes through LDS in full 256-byte
+//     rows, filled by a fifth, loader-only wave with LDS-DMA (4 rows per instruction, 16-byte chunk XOR (row & 15) on
+//     the SOURCE address so that the consumers' ds_read_b128 fragment reads are conflict-free).  The loader's DMA has a
+//     vmcnt of its own: the consumers' counted waits see weight loads only (hipcc drains everything when plain loads
+//     and LDS-DMA share a loop), and the x prefetch distance is independent of the weight stages;
+//   * one raw s_barrier per super-step (it does not drain VMEM): it publishes x chunk j and frees the buffer of j-1.
+// Few column tiles (N = 4096: 32 tiles of 128 columns) are cut along K into `ks` slices, one workgroup each, that write
+// fp32 slabs in accumulator order (1 KB per wave-store), write-through (sc1: the bytes are at the memory side when the
+// store is counted off vmcnt, so no L2 write-back fence is needed -- a release fence per workgroup made the launch twice
+// as long).  The slices of a tile then draw tickets from a per-tile counter; the workgroup that draws the last one reads
+// ALL slabs back with sc1 loads (past its own L1/L2, wherever the other slices ran), sums them in slice order -- the
+// result does not depend on who arrived last -- applies the epilogue and leaves the counter at zero for the next call.  gemm_rows_reduce_kernel is the same sum as a second launch
+// (diagnostics: eagle_debug_set_rows).
+#include "common.h"
+
+#define GR_NW 4                         // consumer waves per workgroup
+#define GR_COUNTER_BYTES 16384          // head of the workspace: one arrival counter per column tile (<= 4096 tiles split)
+#define GR_EPI_LINEAR 0
+#define GR_EPI_SILU_MUL 1
+#define GR_KEEP_RESIDENT 0x100          // accepted and ignored: this path always streams W non-temporally
+
+typedef __attribute__((ext_vector_type(4))) unsigned int gr_u32x4;
+
+struct RowsArgs {
+  const bf16_t* x0; const int64_t* idx0; int64_t ld0; int K0;
+  const int64_t* ind0; int ind_n; int64_t idx0_bstride;   // idx0 row = idx0[(m/ind_n)*bstride + ind0[m%ind_n]]
+  const bf16_t* x1; const int64_t* idx1; int64_t ld1;
+  const bf16_t* W; const bf16_t* W2; int64_t ldw;
+  const bf16_t* bias; const bf16_t* res; int64_t ldr;
+  bf16_t* out; int64_t ldo;
+  int M, N, K;             // N = output columns (SiLU*up: rows of W and of W2 each)
+  int tiles;               // column tiles
+  int ks, kchunk;          // K slices; super-steps (128 k) per slice
+  float* slab;             // ks > 1: [ks][tiles][GR_NW][MT*RT][64] f32x4
+  int* counters;           // ks > 1 and in-launch reduction: [tiles], zero on entry, zero on exit
+  int rotate;              // K-walk stagger between neighbouring column tiles, in super-steps (0: none)
+};
+
+template <int RT, int EPI> struct RowsGeom {
+  static constexpr int RTW = (EPI == GR_EPI_SILU_MUL) ? RT / 2 : RT;   // 16-column output tiles per wave
+  static constexpr int BN = GR_NW * RTW * 16;                          // output columns per workgroup
+};
+
+// acc[t][r] = y[m = mt*16 + r16][n = tile*BN + (w*RTW + u)*16 + 4g + r]  (SiLU: t = 2u gate, 2u+1 up)
+template <int RT, int EPI>
+__device__ __forceinline__ void rows_epilogue(const RowsArgs& p, int tile, int w, int mt, const f32x4 (&acc)[RT], int lane) {
+  using G = RowsGeom<RT, EPI>;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int m = mt * 16 + r16;
+  if (m >= p.M) return;
+#pragma unroll
+  for (int u = 0; u < G::RTW; ++u) {
+    const int nb = tile * G::BN + (w * G::RTW + u) * 16 + 4 * g;
+    if (nb >= p.N) continue;
+    float y[4];
+    if (EPI == GR_EPI_SILU_MUL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float gt = rbf(acc[2 * u][r]), up = rbf(acc[2 * u + 1][r]);
+        y[r] = rbf(gt / (1.0f + __expf(-gt))) * up;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = nb + r;
+        float v = acc[u][r];
+        if (p.bias && n < p.N) v += bf2f(p.bias[n]);
+        v = rbf(v);
+        if (p.res && n < p.N) v = v + bf2f(p.res[(int64_t)m * p.ldr + n]);
+        y[r] = v;
+      }
+    }
+    bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
+    if (nb + 3 < p.N && ((p.ldo | nb) & 3) == 0) {
+      uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+      *reinterpret_cast<uint2*>(o) = v;
+    } else {
+      for (int r = 0; r < 4; ++r) if (nb + r < p.N) o[r] = f2bf(y[r]);
+    }
+  }
+}
+
+// MT 16-row activation tiles (M <= 16*MT), RT 16-row weight tiles per consumer wave, S weight register stages,
+// XS activation LDS buffers of MT*16 rows x 128 k.
+template <int MT, int RT, int EPI, int S, int XS, int NL>
+__global__ __launch_bounds__((GR_NW + NL) * 64) void gemm_rows_stream_kernel(RowsArgs p) {
+  using G = RowsGeom<RT, EPI>;
+  constexpr int XBYTES = MT * 16 * 256;                  // one x chunk: MT*16 rows of 128 bf16
+  constexpr int XOPS = MT * 4 / NL;                      // DMA instructions per chunk and loader wave (4 rows each)
+  static_assert((MT * 4) % NL == 0, "loader waves share a chunk evenly");
+  static_assert((XS - 2) * XOPS <= 63, "vmcnt immediate");
+  __shared__ __attribute__((aligned(256))) unsigned char xl[XS * XBYTES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // consecutive ids run on ONE XCD (dispatch is round-robin over the 8 XCDs): the slices of a tile share an L2, which is
+  // where the last arriver reads their slabs fastest; a speed choice only
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
+  const int id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
+  const int slice = id % p.ks, tile = id / p.ks;
+  const int nj_all = p.K >> 7;
+  const int j_beg = slice * p.kchunk;
+  const int nj = min(p.kchunk, nj_all - j_beg);          // >= 1 (launcher)
+  // Column tiles walk their K slice from staggered starting points (and wrap): workgroups that run side by side then
+  // read different 256-byte columns of the weight rows instead of marching through the same HBM channels in step.
+  const int rot = p.rotate ? (tile * p.rotate) % nj : 0;
+  auto kstep = [&](int j) { const int jj = j + rot; return jj >= nj ? jj - nj : jj; };
+
+  const bool loader = wave >= GR_NW;
+  f32x4 acc[MT][RT];
+  if (loader) {
+    // ---------------- loader wave(s): x chunks -> LDS ----------------
+    const int lrow = lane >> 4, slot = lane & 15, li = wave - GR_NW;
+    const bf16_t* pa[XOPS];
+    const bf16_t* pb[XOPS];
+#pragma unroll
+    for (int i = 0; i < XOPS; ++i) {
+      const int row = 4 * (li * XOPS + i) + lrow;
+      const int m = row < p.M ? row : p.M - 1;
+      int64_t ra, rb;
+      if (p.ind0) ra = p.idx0[(int64_t)(m / p.ind_n) * p.idx0_bstride + p.ind0[m % p.ind_n]];
+      else ra = p.idx0 ? p.idx0[m] : m;
+      rb = p.idx1 ? p.idx1[m] : m;
+      const int ch = slot ^ (row & 15);
+      pa[i] = p.x0 + ra * p.ld0 + ch * 8;
+      pb[i] = p.x1 ? (p.x1 + rb * p.ld1 + ch * 8 - p.K0) : pa[i];
+    }
+    auto issue = [&](int j) {
+      const int k = (j_beg + kstep(j)) << 7;
+      const bool second = k >= p.K0;
+      unsigned char* dst = xl + (j % XS) * XBYTES;
+#pragma unroll
+      for (int i = 0; i < XOPS; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((second ? pb[i] : pa[i]) + k),
+                                         (__attribute__((address_space(3))) void*)(dst + (li * XOPS + i) * 1024), 16, 0, 0);
+    };
+#pragma unroll
+    for (int c = 0; c < XS - 1; ++c) if (c < nj) issue(c);
+    for (int j = 0; j < nj; ++j) {
+      // chunk j has landed when only the younger chunks j+1 .. j+XS-2 are outstanding (tail: wait for everything)
+      if (XS > 2 && j + XS - 2 < nj) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XS - 2) * XOPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // publishes chunk j; every consumer is done with chunk j-1
+      if (j + XS - 1 < nj) issue(j + XS - 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+  // ---------------- consumer waves: W -> VGPR, MFMA against x fragments from LDS ----------------
+  const int r16 = lane & 15, g = lane >> 4;
+  const bf16_t* wp[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const int u = (EPI == GR_EPI_SILU_MUL) ? (t >> 1) : t;
+    int n = tile * G::BN + (wave * G::RTW + u) * 16 + r16;
+    n = n < p.N ? n : p.N - 1;                           // clamped rows compute values that are never stored
+    const bf16_t* base = (EPI == GR_EPI_SILU_MUL && (t & 1)) ? p.W2 : p.W;
+    wp[t] = base + (int64_t)n * p.ldw + 8 * g + ((int64_t)j_beg << 7);
+  }
+  // Every stage refill is issued unconditionally (past the slice's last super-step it reads one hot line of W, the
+  // same address in every lane) and the main loop body is branch-free: hipcc's counted vmcnt waits are exact only
+  // when the number of loads between a stage's issue and its use is the same on every path.
+  bf16x8 a[S][4][RT];
+  auto load_w = [&](bf16x8 (&st)[4][RT], int j) {
+    const bool live = j < nj;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const bf16_t* src = live ? wp[t] + (kstep(j) << 7) + s * 32 : p.W;
+        st[s][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src));
+      }
+  };
+#pragma unroll
+  for (int st = 0; st < S; ++st) load_w(a[st], st);
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto step = [&](const bf16x8 (&st)[4][RT], int j) {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned char* xb = xl + (j % XS) * XBYTES + r16 * 256;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 xf[MT];
+      const int off = ((4 * s + g) ^ r16) << 4;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(xb + mt * 4096 + off);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[s][t], xf[mt], acc[mt][t], 0, 0, 0);
+    }
+  };
+  const int n_full = nj / S * S;
+  for (int j0 = 0; j0 < n_full; j0 += S) {
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      step(a[st], j0 + st);
+      load_w(a[st], j0 + st + S);
+    }
+  }
+#pragma unroll
+  for (int st = 0; st < S - 1; ++st)
+    if (n_full + st < nj) step(a[st], n_full + st);
+
+  }   // consumer
+
+  if (p.ks == 1) {
+    if (!loader) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) rows_epilogue<RT, EPI>(p, tile, wave, mt, acc[mt], lane);
+    }
+    return;
+  }
+  const int64_t slab_wave = (int64_t)GR_NW * (MT * RT) * 64;                     // f32x4 per (slice, tile)
+  constexpr int WAVE_SLAB = MT * RT * 1024;               // bytes one consumer wave writes
+  if (!loader) {
+    f32x4* sl = reinterpret_cast<f32x4*>(p.slab) + ((int64_t)slice * p.tiles + tile) * slab_wave + wave * (MT * RT) * 64;
+    if (p.counters) {                                    // write-through stores
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sl, 0, WAVE_SLAB, 0x00020000);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          union { f32x4 f; gr_u32x4 u; } cv; cv.f = acc[mt][t];
+          __builtin_amdgcn_raw_buffer_store_b128(cv.u, rs, ((mt * RT + t) * 64 + lane) * 16, 0, 16 /* sc1 */);
+        }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) sl[(mt * RT + t) * 64 + lane] = acc[mt][t];
+    }
+  }
+  if (!p.counters) return;                               // gemm_rows_reduce_kernel follows
+  // ---- in-launch reduction: ticket per tile, the last arriver sums every slab in slice order ----
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave: its slab is written through
+  __syncthreads();                                       // ... all of them; all x reads are done too
+  int* tick = reinterpret_cast<int*>(xl);                // the one LDS array (a second object makes hipcc drain the DMA)
+  if (threadIdx.x == 0) *tick = __hip_atomic_fetch_add(&p.counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*tick != p.ks - 1) return;
+  if (threadIdx.x == 0) __hip_atomic_store(&p.counters[tile], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (loader) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the slab loads below the ticket
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const f32x4* sb = reinterpret_cast<const f32x4*>(p.slab) + (int64_t)tile * slab_wave + wave * (MT * RT) * 64;
+  for (int s2 = 0; s2 < p.ks; ++s2) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sb + (int64_t)s2 * p.tiles * slab_wave), 0, WAVE_SLAB, 0x00020000);
+    gr_u32x4 v[MT * RT];                                   // the whole slab of this wave in flight, then added
+#pragma unroll
+    for (int i = 0; i < MT * RT; ++i)
+      v[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (i * 64 + lane) * 16, 0, 16 /* sc1: EVERY slab load */);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        union { f32x4 f; gr_u32x4 u; } cv; cv.u = v[mt * RT + t];
+        acc[mt][t] += cv.f;
+      }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) rows_epilogue<RT, EPI>(p, tile, wave, mt, acc[mt], lane);
+}
+
+// grid (tiles, MT): block (tile, mt) sums the ks slabs of one 16-row block of a column tile and applies the epilogue
+template <int MT, int RT, int EPI>
+__global__ __launch_bounds__(GR_NW * 64) void gemm_rows_reduce_kernel(RowsArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x, mt = blockIdx.y;
+  if (mt * 16 >= p.M) return;
+  f32x4 acc[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int64_t slab_wave = (int64_t)GR_NW * (MT * RT) * 64;
+  const f32x4* sb = reinterpret_cast<const f32x4*>(p.slab) + (int64_t)tile * slab_wave + (wave * (MT * RT) + mt * RT) * 64 + lane;
+  const int64_t step = (int64_t)p.tiles * slab_wave;
+  int s = 0;
+  for (; s + 4 <= p.ks; s += 4) {                          // four slices in flight, added in slice order
+    f32x4 v[4][RT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) v[u][t] = sb[(s + u) * step + t * 64];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] += v[u][t];
+  }
+  for (; s < p.ks; ++s)
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] += sb[s * step + t * 64];
+  rows_epilogue<RT, EPI>(p, tile, wave, mt, acc, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+static int g_rows_target_wg = 0;    // 0: by shape; diagnostics (eagle_debug_set_rows): workgroups the K split aims for
+static int g_rows_min_steps = 4;    // least super-steps per K slice
+static int g_rows_stages = 0;       // 0: default; 2 / 3 / 4 weight register stages (+ 0x10 * (1 + stagger): K-walk stagger override)
+static int g_rows_rotate = 1;
+static int g_rows_two_launch = 0;  // 1: sum the slabs in a second launch (gemm_rows_reduce_kernel)
+extern "C" void eagle_debug_set_rows(int target_wg, int min_steps, int stages) {
+  g_rows_target_wg = target_wg > 0 ? target_wg : 0;
+  g_rows_min_steps = min_steps > 0 ? min_steps : 4;
+  g_rows_two_launch = (stages >> 8) & 1;
+  stages &= 0xff;
+  g_rows_stages = stages & 15;
+  g_rows_rotate = (stages >> 4) ? (stages >> 4) - 1 : 1;
+}
+static int gr_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+struct RowsPlan { int mt, tiles, ks, kchunk; };
+static RowsPlan gr_plan(int M, int N, int K, int epi) {
+  RowsPlan pl;
+  const int mt = (M + 15) / 16;
+  pl.mt = mt <= 2 ? 2 : mt <= 4 ? 4 : mt <= 6 ? 6 : 8;
+  const int bn = (epi == GR_EPI_SILU_MUL) ? RowsGeom<2, GR_EPI_SILU_MUL>::BN : RowsGeom<2, GR_EPI_LINEAR>::BN;
+  pl.tiles = (N + bn - 1) / bn;
+  const int nj = K >> 7;
+  const int target = g_rows_target_wg ? g_rows_target_wg : gr_num_cus() * (pl.mt >= 6 ? 1 : 2);
+  int ks = (target + pl.tiles / 2) / pl.tiles;           // nearest count of slices
+  const int ks_max = nj / g_rows_min_steps;
+  if (ks > ks_max) ks = ks_max;
+  if (ks < 1 || pl.tiles * 4 > GR_COUNTER_BYTES) ks = 1;
+  pl.kchunk = (nj + ks - 1) / ks;
+  pl.ks = (nj + pl.kchunk - 1) / pl.kchunk;              // every slice non-empty
+  return pl;
+}
+
+extern "C" int64_t eagle_gemm_rows_workspace_bytes(int M, int N, int K, int epi) {
+  epi &= ~GR_KEEP_RESIDENT;
+  if (M < 1 || M > 128 || N < 1 || K < 128 || (K & 127) || (epi != GR_EPI_LINEAR && epi != GR_EPI_SILU_MUL)) return 0;
+  const RowsPlan pl = gr_plan(M, N, K, epi);
+  if (pl.ks == 1) return 0;
+  return GR_COUNTER_BYTES + (int64_t)pl.ks * pl.tiles * GR_NW * (pl.mt * 2) * 64 * 16;
+}
+
+template <int MT, int EPI, int S>
+static int gr_launch_s(const RowsArgs& a, hipStream_t st) {
+  constexpr int XS = 4;      // x chunks in LDS: the loader runs 3 super-steps ahead (an L2 hit under a full HBM stream takes > 1 us)
+  constexpr int NL = MT <= 2 ? 1 : MT <= 4 ? 2 : 4;
+  hipLaunchKernelGGL((gemm_rows_stream_kernel<MT, 2, EPI, S, XS, NL>), dim3(a.tiles * a.ks), dim3((GR_NW + NL) * 64), 0, st, a);
+  int rc = eagle_check_launch();
+  if (rc || a.ks == 1 || a.counters) return rc;
+  hipLaunchKernelGGL((gemm_rows_reduce_kernel<MT, 2, EPI>), dim3(a.tiles, (a.M + 15) / 16), dim3(GR_NW * 64), 0, st, a);
+  return eagle_check_launch();
+}
+template <int MT, int EPI>
+static int gr_launch(const RowsArgs& a, hipStream_t st) {
+  if (g_rows_stages == 2) return gr_launch_s<MT, EPI, 2>(a, st);
+  if constexpr (MT <= 4) { if (g_rows_stages == 4) return gr_launch_s<MT, EPI, 4>(a, st); }
+  return gr_launch_s<MT, EPI, 3>(a, st);
+}
+template <int EPI>
+static int gr_launch_mt(const RowsArgs& a, int mt, hipStream_t st) {
+  switch (mt) {
+    case 2: return gr_launch<2, EPI>(a, st);
+    case 4: return gr_launch<4, EPI>(a, st);
+    case 6: return gr_launch<6, EPI>(a, st);
+    default: return gr_launch<8, EPI>(a, st);
+  }
+}
+
+static inline bool gr_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// See include/eagle_hip.h for the contract.
+extern "C" int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int K0,
+                                    const int64_t* ind0, int ind_n, int64_t idx0_bstride,
+                                    const void* x1, const int64_t* idx1, int64_t ld1,
+                                    const void* W, const void* W2, int64_t ldw, const void* bias,
+                                    const void* res, int64_t ldr, void* out, int64_t ldo,
+                                    int M, int N, int K, int epi, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  if (!x0 || !W || !out) return EAGLE_ERR_ARG;
+  epi &= ~GR_KEEP_RESIDENT;
+  if (epi != GR_EPI_LINEAR && epi != GR_EPI_SILU_MUL) return EAGLE_ERR_ARG;
+  if (ind0 && (!idx0 || ind_n < 1)) return EAGLE_ERR_ARG;
+  if (epi == GR_EPI_SILU_MUL && (!W2 || bias || res)) return EAGLE_ERR_ARG;
+  if (M < 1 || M > 128 || N < 1 || K < 128 || (K & 127)) return EAGLE_ERR_SHAPE;
+  if (x1) { if (K0 <= 0 || K0 >= K || (K0 & 127) || (ld1 & 7) || !gr_al16(x1)) return EAGLE_ERR_SHAPE; }
+  else K0 = K;
+  if ((ld0 & 7) || (ldw & 7) || ldw < K || !gr_al16(x0) || !gr_al16(W) || (W2 && !gr_al16(W2))) return EAGLE_ERR_SHAPE;
+  if (ld0 < K0 && !idx0 && M > 1) return EAGLE_ERR_SHAPE;
+  if (ldo < N || (res && ldr < N)) return EAGLE_ERR_SHAPE;
+  const RowsPlan pl = gr_plan(M, N, K, epi);
+  const int64_t need = pl.ks == 1 ? 0 : GR_COUNTER_BYTES + (int64_t)pl.ks * pl.tiles * GR_NW * (pl.mt * 2) * 64 * 16;
+  if (need && (!workspace || workspace_bytes < need || !gr_al16(workspace))) return EAGLE_ERR_ARG;
+  RowsArgs a;
+  a.x0 = (const bf16_t*)x0; a.idx0 = idx0; a.ld0 = ld0; a.K0 = K0;
+  a.ind0 = ind0; a.ind_n = ind_n; a.idx0_bstride = idx0_bstride;
+  a.x1 = (const bf16_t*)x1; a.idx1 = idx1; a.ld1 = ld1;
+  a.W = (const bf16_t*)W; a.W2 = (const bf16_t*)W2; a.ldw = ldw;
+  a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
+  a.out = (bf16_t*)out; a.ldo = ldo;
+  a.M = M; a.N = N; a.K = K;
+  a.rotate = g_rows_rotate;
+  a.tiles = pl.tiles; a.ks = pl.ks; a.kchunk = pl.kchunk;
+  a.slab = workspace ? (float*)((char*)workspace + GR_COUNTER_BYTES) : nullptr;
+  a.counters = (pl.ks > 1 && !g_rows_two_launch) ? (int*)workspace : nullptr;
+  return epi == GR_EPI_SILU_MUL ? gr_launch_mt<GR_EPI_SILU_MUL>(a, pl.mt, stream) : gr_launch_mt<GR_EPI_LINEAR>(a, pl.mt, stream);
+}

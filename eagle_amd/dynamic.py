@@ -49,6 +49,7 @@ class EagleDynamicDrafter:
         self.dev, self.D = dev, model.config.hidden_size
         self.keep_debug, self.debug = keep_debug, []
         self.wide_head_rows = 32
+        self.rows_head_max = 64
         V = lm_head_weight.shape[0]
         self.caches = [model.new_cache(B, self.cap, dev) for _ in model.layers]      # private: forward() never touches them
         model.set_cache_residency(self.lm_head)
@@ -93,7 +94,9 @@ class EagleDynamicDrafter:
 
     # ------------------------------------------------------------------ draft side
     def _head(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int):
-        if rows >= self.wide_head_rows and self.D % 64 == 0:
+        if self.model.rows_min <= rows <= self.rows_head_max and self.D % 128 == 0:
+            logits = ops.linear_rows(x, self.lm_head, idx0=idx, M=rows)          # decode batches: row-batch weight stream
+        elif rows >= self.wide_head_rows and self.D % 64 == 0:
             logits = ops.gemm_nt(x if idx is None else x.index_select(0, idx[:rows]), self.lm_head)
         else:
             logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows, resident=self.model._keep_resident(self.lm_head))

@@ -147,6 +147,10 @@ class Llama2Model(nn.Module):
         self._rows_out: List[int] = []                   # most rows of each buffer ever handed out as a view
         self._packed = {}
         self._weight_epoch = 0                           # part of every derived-weight cache key
+        # forwards of rows_min .. 128 rows run on the row-batch weight stream (eagle_gemm_rows_bf16); below, on the
+        # per-step weight-stream kernels.  Tests that compare a batch with per-request runs bit for bit set it to 1, so
+        # that both sides sum K in the same order.
+        self.rows_min = 17
         self._resident = None                            # (epoch, {data_ptr}) of the matrices to keep cache-resident
         self._resident_args = None
         self._rope = None
@@ -313,6 +317,13 @@ class Llama2Model(nn.Module):
             # indirection of the weight-stream GEMM covers one 64-row pass)
             emb_idx = ops.tree_gather_ids(emb_idx, emb_ind, B=B, batch_stride=emb_bstride).reshape(-1)
             emb_ind, emb_bstride = None, 0
+        # decode batches (a batch of requests stepping through the tree together: 17..128 rows): every projection is one
+        # weight pass of the row-batch weight stream (W to registers, x through LDS, K split where the matrix is small)
+        mid = self.rows_min <= M <= ops.ROWS_MAX and self.config.hidden_size % 128 == 0 and self.config.intermediate_size % 128 == 0 \
+            and hid.dim() == 2 and hid.stride(1) == 1
+        if mid:
+            return self._forward_rows_mid(emb_idx, hid, hid_idx, M, B, q_len, pos, past_dev, max_kv, tmask, pad, caches,
+                                          past_host, past_off0, pos_off, pos_stride, emb_ind, emb_bstride, cos, sin)
         # prompts and other wide row blocks without row gathers take the LDS-tiled MFMA GEMM for every
         # projection: one weight pass instead of one per 64 rows of the weight-stream kernel
         wide_rest = M > 64 and x_width_ok(self, hid)                  # qkv / o / gate|up / down: no row gathers involved
@@ -355,6 +366,35 @@ class Llama2Model(nn.Module):
             else:
                 x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x,
                                       resident=self._keep_resident(layer.mlp.down_proj.weight))
+        return x
+
+    def _forward_rows_mid(self, emb_idx, hid, hid_idx, M, B, q_len, pos, past_dev, max_kv, tmask, pad, caches,
+                          past_host, past_off0, pos_off, pos_stride, emb_ind, emb_bstride, cos, sin):
+        """_forward_rows for 17..128 rows: the same chain on eagle_gemm_rows_bf16 (row gathers, the cat of fc, the residual
+        adds and SiLU*up all in the GEMM's loader / epilogue; the RMSNorms as their own small kernels)."""
+        dev = hid.device
+        H, HK, hd = self._dims()
+        emb_w = self.embed_tokens.weight
+        x = ops.linear_rows(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
+                            ind0=emb_ind, idx0_bstride=emb_bstride)
+        for li, layer in enumerate(self.layers):
+            a = layer.self_attn
+            cache = caches[li]
+            xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
+            qkv = ops.linear_rows(xin, self._packed_weights(li))
+            attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
+            ws = self._attn_workspace(B, H, (past_host + q_len) if past_host is not None else max_kv, dev)
+            for r0 in range(0, q_len, 16):
+                mq = min(16, q_len - r0)
+                bound = (past_host + r0 + mq) if past_host is not None else max_kv
+                ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, past_off0 + r0, tmask, pad, attn, ws,
+                                   self._err, B, mq, H, HK, hd, bound, True, q_len, r0, pos_off, pos_stride)
+            x = ops.linear_rows(attn, a.o_proj.weight, res=x)
+            n = ops.rmsnorm(x, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
+            wgu = self._stacked_mlp(li)
+            inter = wgu.shape[0] // 2
+            act = ops.linear_rows(n, wgu[:inter], W2=wgu[inter:])
+            x = ops.linear_rows(act, layer.mlp.down_proj.weight, res=x)
         return x
 
     # ------------------------------------------------------------------ forward

@@ -68,6 +68,59 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
+ROWS_MAX = 128   # rows one eagle_gemm_rows_bf16 call takes
+_rows_ws_cache = {}
+
+
+def _rows_workspace(nbytes: int, device) -> torch.Tensor:
+    """Workspace of eagle_gemm_rows_bf16, one per (device, stream): its head holds the per-tile arrival counters, which must
+    be zero on entry and are left zero by every call -- so the buffer is zero-filled once, when it is (re)allocated."""
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    w = _rows_ws_cache.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.zeros(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _rows_ws_cache[key] = w
+    return w
+
+
+def linear_rows(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                res: Optional[torch.Tensor] = None, W2: Optional[torch.Tensor] = None,
+                idx0: Optional[torch.Tensor] = None, x1: Optional[torch.Tensor] = None,
+                idx1: Optional[torch.Tensor] = None, M: Optional[int] = None,
+                out: Optional[torch.Tensor] = None, ind0: Optional[torch.Tensor] = None,
+                idx0_bstride: int = 0) -> torch.Tensor:
+    """linear_skinny's product for a decode batch of up to 128 rows in ONE weight pass (eagle_gemm_rows_bf16): W straight
+    to registers, x through LDS, K split over workgroups where the matrix has few column tiles.  W (and W2) [N, K] with
+    any row stride that is a multiple of 8; K (and the cat boundary) multiples of 128."""
+    _chk(x, "x"), _chk(W, "W")
+    N, K = W.shape
+    K0 = x.shape[-1]
+    if x1 is not None:
+        _chk(x1, "x1")
+        if K0 + x1.shape[-1] != K:
+            raise ValueError(f"cat width {K0}+{x1.shape[-1]} != K={K}")
+    elif K0 != K:
+        raise ValueError(f"x width {K0} != K={K}")
+    if M is None:
+        M = idx0.numel() if idx0 is not None else x.shape[0]
+    if x.stride(-1) != 1 or W.stride(1) != 1 or (W2 is not None and (W2.stride(1) != 1 or W2.stride(0) != W.stride(0) or W2.shape != W.shape)):
+        raise ValueError("x rows, W and W2 must be contiguous along K; W2 shaped and strided as W")
+    for i in (idx0, idx1, ind0):
+        if i is not None and (i.dtype != torch.int64 or (not i.is_contiguous() and not (i is idx0 and ind0 is not None))):
+            raise TypeError("row index arrays must be contiguous int64")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=x.device)
+    epi = EPI_SILU_MUL if W2 is not None else EPI_LINEAR
+    nbytes = query("eagle_gemm_rows_workspace_bytes", M, N, K, epi)
+    ws = _rows_workspace(nbytes, x.device) if nbytes else None
+    call("eagle_gemm_rows_bf16", ptr(x), ptr(idx0), x.stride(0) if x.dim() > 1 else K0, K0,
+         ptr(ind0), (ind0.numel() if ind0 is not None else 0), idx0_bstride,
+         ptr(x1), ptr(idx1), (x1.stride(0) if x1 is not None else 0),
+         ptr(W), ptr(W2), W.stride(0), ptr(bias), ptr(res), (res.stride(0) if res is not None else 0),
+         ptr(out), out.stride(0), M, N, K, epi, ptr(ws), (ws.numel() if ws is not None else 0), stream())
+    return out
+
+
 def pick_resident_weights(weights, budget_bytes: int):
     """Smallest-first subset of ``weights`` whose bytes fit ``budget_bytes`` (the Infinity Cache share a
     draft forward's small matrices may occupy); groups (tuples) are taken or left whole."""

@@ -59,6 +59,7 @@ class EagleDrafter:
         self.cap = (max_ctx + self.W + self.n_fwd + 255) // 256 * 256
         self.dev, self.D = dev, model.config.hidden_size
         self.wide_head_rows = 32      # lm_head row blocks from this many rows on take the MFMA GEMM (one weight pass)
+        self.rows_head_max = 64       # ... and up to this many the row-batch weight stream (eagle_gemm_rows_bf16)
         # static bound on stable_len + tree rows handed to the attention launcher (grid size); a caller
         # that knows a tighter bound for the coming cycles may lower it (must stay >= the true length)
         self.kv_bound = self.cap
@@ -100,7 +101,11 @@ class EagleDrafter:
     # -------------------------------------------------------------- draft side
     def _head_topk(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int, row0: int, n: int):
         """top-k(lm_head(x[idx])) -> flat rows [row0, row0+n) of every request."""
-        if rows >= self.wide_head_rows and self.D % 64 == 0:
+        if self.model.rows_min <= rows <= self.rows_head_max and self.D % 128 == 0:
+            # decode batches: the row-batch weight stream (gather fused; 32 rows of the 151936-row head 257 vs 328 us on
+            # the LDS-tiled kernels, tools/rows2_bench.py); past ~64 rows its x re-reads cost what the tiles' do
+            logits = ops.linear_rows(x, self.lm_head, idx0=idx, M=rows)
+        elif rows >= self.wide_head_rows and self.D % 64 == 0:
             # wide batches: one weight pass on the MFMA GEMM (from 32 rows on it beats the weight-stream kernel, which
             # passes over the weights once per 32 rows: 304 vs 520 us at 32 rows of the 151936-row head)
             logits = ops.gemm_nt(x if idx is None else x.index_select(0, idx[:rows]), self.lm_head)

@@ -48,6 +48,23 @@ int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int
                            const void* res, int64_t ldr, void* out, int64_t ldo,
                            int M, int N, int K, int epi, eagle_stream_t stream);
 
+/* The same product for decode BATCHES, 1 <= M <= 128 rows (a batch of requests stepping through the draft tree together:
+ * 32 requests x 1 or 4 tree rows): one weight pass for all rows.  Operands and epilogues as eagle_gemm_skinny_bf16
+ * (no norm_eps: run eagle_rmsnorm_fwd_bf16 first); W [N, K] with row stride ldw (W2 too), K % 128 == 0, K0 % 128 == 0.
+ * Few column tiles are cut along K; the fp32 partial sums go through `workspace`
+ * (eagle_gemm_rows_workspace_bytes(M, N, K, epi) bytes, 16-byte aligned, may be NULL when that is 0) and the last
+ * workgroup of a tile to arrive sums them in slice order (deterministic).  The first 16 KiB of the workspace hold the
+ * arrival counters: they must be ZERO before the first call and every call leaves them zero; calls that share a
+ * workspace must not overlap (one stream, or one workspace per stream).  Replaces the same nn.Linear calls (eagle/llama2.py:222-224, :280, :317, :542; lm_head eagle/train.py:215-228)
+ * at batch sizes where eagle_gemm_skinny_bf16 would stream the weights once per 32 or 64 rows. */
+int64_t eagle_gemm_rows_workspace_bytes(int M, int N, int K, int epi);
+int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int K0,
+                         const int64_t* ind0, int ind_n, int64_t idx0_bstride,
+                         const void* x1, const int64_t* idx1, int64_t ld1,
+                         const void* W, const void* W2, int64_t ldw, const void* bias,
+                         const void* res, int64_t ldr, void* out, int64_t ldo,
+                         int M, int N, int K, int epi, void* workspace, int64_t workspace_bytes, eagle_stream_t stream);
+
 /* C[M,N] = epilogue(A[M,K] . B[N,K]^T): LDS-tiled MFMA GEMM (128x128x64 tiles, LDS-DMA staging)
  * for training-size M.  (+bias[N]) (+res[M,N] bf16); C is bf16 (out_f32 = 0) or fp32 (1);
  * accumulate != 0: C += result.  K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned bases.
@@ -353,6 +370,10 @@ void eagle_debug_set_gemm8(int mode);
  * K = 4096 (streaming otherwise), 3 = by shape (default); blocks_per_cu / min_rows > 0 override the streaming
  * kernel's grid sizing. */
 void eagle_debug_set_skinny_variant(int variant, int blocks_per_cu, int min_rows);
+/* eagle_gemm_rows_bf16: target_wg > 0 = workgroups the K split aims for (0 = by shape), min_steps = least 128-wide K
+ * super-steps per slice (default 4); stages: bits 0-3 = 2 / 3 / 4 weight register stages (0 = default 3), bits 4-7 =
+ * 1 + K-walk stagger of neighbouring column tiles (0 = default stagger 1), bit 8 = sum the partial sums in a second launch. */
+void eagle_debug_set_rows(int target_wg, int min_steps, int stages);
 
 #ifdef __cplusplus
 }

@@ -20,14 +20,17 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _model(dims, w):
+def _model(dims, w, rows_min=None):
     from eagle_amd.config import DraftConfig
     from eagle_amd.llama2 import Llama2Model
     cfg = DraftConfig(hidden_size=dims.hidden, intermediate_size=dims.inter, num_attention_heads=dims.heads,
                       num_key_value_heads=dims.kv_heads, vocab_size=dims.vocab)
     m = Llama2Model(cfg)
     m.load_state_dict(w, strict=True)
-    return m.to(BF).to(dev()).eval()
+    m = m.to(BF).to(dev()).eval()
+    if rows_min is not None:
+        m.rows_min = rows_min      # batch and per-request runs on the same kernel family: rows are independent of their neighbours
+    return m
 
 
 def test_row_lse_matches_logsumexp():
@@ -185,8 +188,8 @@ def test_batched_dynamic_tree_matches_oracle_and_batch_1_per_request(S, k, T):
     lm_head = (torch.randn(dims.vocab, dims.hidden, generator=g) * 0.3).to(BF).to(d)
     ctxs = [23, 5, 70]
     B = len(ctxs)
-    batched = EagleDynamicDrafter(_model(dims, w), lm_head, steps=S, topk=k, num_draft_tokens=T, max_ctx=256, keep_debug=True, batch=B)
-    singles = [EagleDynamicDrafter(_model(dims, w), lm_head, steps=S, topk=k, num_draft_tokens=T, max_ctx=256) for _ in range(B)]
+    batched = EagleDynamicDrafter(_model(dims, w, 1), lm_head, steps=S, topk=k, num_draft_tokens=T, max_ctx=256, keep_debug=True, batch=B)
+    singles = [EagleDynamicDrafter(_model(dims, w, 1), lm_head, steps=S, topk=k, num_draft_tokens=T, max_ctx=256) for _ in range(B)]
     hid = [torch.randn(c, dims.hidden, generator=g).to(BF).to(d) for c in ctxs]
     tok = [torch.randint(0, dims.vocab, (c + 1,), generator=g).to(d) for c in ctxs]
     with torch.no_grad():

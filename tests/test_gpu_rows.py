@@ -1,0 +1,95 @@
+"""eagle_gemm_rows_bf16 (decode batches of up to 128 rows in one weight pass) against fp32 torch on the same inputs, through
+the C ABI: every row-tile count, split and unsplit K, both epilogues, gathered / concatenated / doubly indirected rows."""
+import pytest
+import torch
+
+from test_gpu_parity import BF, close, dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N,K", [(17, 4096, 4096), (32, 4096, 4096), (33, 6144, 4096), (64, 4096, 8192), (84, 4096, 4096),
+                                   (96, 4096, 12288), (128, 4096, 4096), (128, 24576, 4096), (128, 151936, 4096), (32, 151936, 4096),
+                                   (1, 128, 128), (20, 1000, 256), (128, 200, 384), (50, 72, 1024)])
+def test_gemm_rows_linear(M, N, K):
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(M * 131 + N + K)
+    x = (torch.randn(M, K, generator=g)).to(BF).to(dev())
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(dev())
+    b = torch.randn(N, generator=g).to(BF).to(dev())
+    r = torch.randn(M, N, generator=g).to(BF).to(dev())
+    ref = x.float() @ W.float().t()
+    close(ops.linear_rows(x, W), ref, what="rows plain")
+    ref2 = (ref + b.float()).to(BF).float() + r.float()
+    close(ops.linear_rows(x, W, bias=b, res=r), ref2, what="rows bias+res")
+
+
+@pytest.mark.parametrize("M,I,K", [(32, 12288, 4096), (128, 12288, 4096), (84, 11008, 4096), (24, 200, 128), (100, 64, 512)])
+def test_gemm_rows_silu_mul(M, I, K):
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(7 + M)
+    x = torch.randn(M, K, generator=g).to(BF).to(dev())
+    Wgu = (torch.randn(2 * I, K, generator=g) / K ** 0.5).to(BF).to(dev())     # stacked gate|up: W2 is a view of it
+    gt = (x.float() @ Wgu[:I].float().t()).to(BF)
+    up = (x.float() @ Wgu[I:].float().t()).to(BF)
+    ref = torch.nn.functional.silu(gt) * up
+    close(ops.linear_rows(x, Wgu[:I], W2=Wgu[I:]), ref, what="rows silu*up")
+
+
+def test_gemm_rows_gather_concat_and_double_indirection():
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(11)
+    V, D, M = 1000, 256, 70
+    emb = torch.randn(V, D, generator=g).to(BF)
+    hid = torch.randn(90, D, generator=g).to(BF)
+    W = (torch.randn(D, 2 * D, generator=g) / (2 * D) ** 0.5).to(BF)
+    bias = torch.randn(D, generator=g).to(BF)
+    ids = torch.randint(0, V, (M,), generator=g)
+    prow = torch.randint(0, 90, (M,), generator=g)
+    ref = torch.cat([emb[ids], hid[prow]], -1).float() @ W.float().t() + bias.float()
+    y = ops.linear_rows(emb.to(dev()), W.to(dev()), bias=bias.to(dev()), idx0=ids.to(dev()), x1=hid.to(dev()),
+                        idx1=prow.to(dev()), M=M)
+    close(y, ref, what="rows gather+concat")
+    B, n = 24, 4
+    hid2 = torch.randn(B * n, D, generator=g).to(BF)
+    flat = torch.randint(0, V, (B, 7, 10), generator=g)           # flat top-k table per request
+    tree_idx = torch.tensor([0, 1, 2, 10])
+    row0 = 2
+    ids2 = flat[:, row0:].reshape(B, -1)[:, tree_idx]             # [B, n]
+    ref = torch.cat([emb[ids2.reshape(-1)], hid2], -1).float() @ W.float().t()
+    fd = flat.to(dev())
+    y = ops.linear_rows(emb.to(dev()), W.to(dev()), idx0=fd[:, row0], x1=hid2.to(dev()), M=B * n,
+                        ind0=tree_idx.to(dev()), idx0_bstride=7 * 10)
+    close(y, ref, what="rows double indirection")
+
+
+def test_gemm_rows_every_split_and_stage_setting():
+    """The diagnostic knobs select the K split and the register stages: every combination gives the same product."""
+    from eagle_amd import ops
+    from eagle_amd._hip import lib
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 100, 512, 2048
+    x = torch.randn(M, K, generator=g).to(BF).to(dev())
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(dev())
+    r = torch.randn(M, N, generator=g).to(BF).to(dev())
+    ref = (x.float() @ W.float().t()).to(BF).float() + r.float()
+    try:
+        for target in (1, 8, 16, 64):
+            for steps in (1, 2, 4):
+                for stages in (2, 3, 4, 0x103, 0x13, 0x33):
+                    lib().eagle_debug_set_rows(target, steps, stages)
+                    close(ops.linear_rows(x, W, res=r), ref, what="rows knobs")
+                    close(ops.linear_rows(x[:30], W, res=r[:30]), ref[:30], what="rows knobs")
+    finally:
+        lib().eagle_debug_set_rows(0, 0, 0)
+
+
+def test_gemm_rows_rejects_bad_shapes():
+    from eagle_amd import ops
+    from eagle_amd._hip import HipKernelError
+    W = torch.zeros(16, 192, dtype=BF, device=dev())
+    with pytest.raises(HipKernelError):
+        ops.linear_rows(torch.zeros(2, 192, dtype=BF, device=dev()), W)       # K % 128 != 0
+    W = torch.zeros(16, 256, dtype=BF, device=dev())
+    with pytest.raises(HipKernelError):
+        ops.linear_rows(torch.zeros(129, 256, dtype=BF, device=dev()), W)     # more than 128 rows
