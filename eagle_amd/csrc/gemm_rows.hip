@@ -15,12 +15,12 @@
 //     and LDS-DMA share a loop), and the x prefetch distance is independent of the weight stages;
 //   * one raw s_barrier per super-step (it does not drain VMEM): it publishes x chunk j and frees the buffer of j-1.
 // Few column tiles (N = 4096: 32 tiles of 128 columns) are cut along K into `ks` slices, one workgroup each, that write
-// fp32 slabs in accumulator order (1 KB per wave-store), write-through (sc1: the bytes are at the memory side when the
-// store is counted off vmcnt, so no L2 write-back fence is needed -- a release fence per workgroup made the launch twice
-// as long).  The slices of a tile then draw tickets from a per-tile counter; the workgroup that draws the last one reads
-// ALL slabs back with sc1 loads (past its own L1/L2, wherever the other slices ran), sums them in slice order -- the
-// result does not depend on who arrived last -- applies the epilogue and leaves the counter at zero for the next call.  gemm_rows_reduce_kernel is the same sum as a second launch
-// (diagnostics: eagle_debug_set_rows).
+// fp32 slabs in accumulator order (1 KB per wave-store); gemm_rows_reduce_kernel, a second launch, sums them in slice
+// order and applies the epilogue.  The in-launch form of that sum is kept behind eagle_debug_set_rows: write-through
+// (sc1) slab stores -- at the memory side when counted off vmcnt, no L2 write-back fence (a release fence per workgroup
+// doubled the launch) -- then a ticket from a per-tile counter; the workgroup that draws the last one reads ALL slabs
+// back with sc1 loads (past its own L1/L2, wherever the other slices ran), sums them in the same slice order and leaves
+// the counter at zero.  It is the slower of the two at these slab sizes (see g_rows_two_launch).
 #include "common.h"
 
 #define GR_NW 4                         // consumer waves per workgroup
@@ -313,11 +313,14 @@ static int g_rows_target_wg = 0;    // 0: by shape; diagnostics (eagle_debug_set
 static int g_rows_min_steps = 4;    // least super-steps per K slice
 static int g_rows_stages = 0;       // 0: default; 2 / 3 / 4 weight register stages (+ 0x10 * (1 + stagger): K-walk stagger override)
 static int g_rows_rotate = 1;
-static int g_rows_two_launch = 0;  // 1: sum the slabs in a second launch (gemm_rows_reduce_kernel)
+// Default: the slabs are summed by a second launch.  Measured at the batch-32 leg's shapes (tools/rows2_trace.sh): a slice
+// writes 16-64 KB, a tile's last arriver would read 128-512 KB alone while the other CUs idle -- o_proj at 32 rows 17.5 us
+// in one launch against 10.2 + 4.0 in two, at 128 rows 38.6 against 22.4 + 5.1.  The in-launch form stays selectable.
+static int g_rows_two_launch = 1;
 extern "C" void eagle_debug_set_rows(int target_wg, int min_steps, int stages) {
   g_rows_target_wg = target_wg > 0 ? target_wg : 0;
   g_rows_min_steps = min_steps > 0 ? min_steps : 4;
-  g_rows_two_launch = (stages >> 8) & 1;
+  g_rows_two_launch = ((stages >> 8) & 1) ? 0 : 1;
   stages &= 0xff;
   g_rows_stages = stages & 15;
   g_rows_rotate = (stages >> 4) ? (stages >> 4) - 1 : 1;

@@ -52,10 +52,10 @@ int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int
  * 32 requests x 1 or 4 tree rows): one weight pass for all rows.  Operands and epilogues as eagle_gemm_skinny_bf16
  * (no norm_eps: run eagle_rmsnorm_fwd_bf16 first); W [N, K] with row stride ldw (W2 too), K % 128 == 0, K0 % 128 == 0.
  * Few column tiles are cut along K; the fp32 partial sums go through `workspace`
- * (eagle_gemm_rows_workspace_bytes(M, N, K, epi) bytes, 16-byte aligned, may be NULL when that is 0) and the last
- * workgroup of a tile to arrive sums them in slice order (deterministic).  The first 16 KiB of the workspace hold the
- * arrival counters: they must be ZERO before the first call and every call leaves them zero; calls that share a
- * workspace must not overlap (one stream, or one workspace per stream).  Replaces the same nn.Linear calls (eagle/llama2.py:222-224, :280, :317, :542; lm_head eagle/train.py:215-228)
+ * (eagle_gemm_rows_workspace_bytes(M, N, K, epi) bytes, 16-byte aligned, may be NULL when that is 0) and a second launch
+ * sums them in slice order (deterministic).  The first 16 KiB of the workspace are arrival counters for the in-launch
+ * form of that sum (diagnostics): they must be ZERO before the first call and every call leaves them zero; calls that
+ * share a workspace must not overlap (one stream, or one workspace per stream).  Replaces the same nn.Linear calls (eagle/llama2.py:222-224, :280, :317, :542; lm_head eagle/train.py:215-228)
  * at batch sizes where eagle_gemm_skinny_bf16 would stream the weights once per 32 or 64 rows. */
 int64_t eagle_gemm_rows_workspace_bytes(int M, int N, int K, int epi);
 int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int K0,
@@ -372,7 +372,7 @@ void eagle_debug_set_gemm8(int mode);
 void eagle_debug_set_skinny_variant(int variant, int blocks_per_cu, int min_rows);
 /* eagle_gemm_rows_bf16: target_wg > 0 = workgroups the K split aims for (0 = by shape), min_steps = least 128-wide K
  * super-steps per slice (default 4); stages: bits 0-3 = 2 / 3 / 4 weight register stages (0 = default 3), bits 4-7 =
- * 1 + K-walk stagger of neighbouring column tiles (0 = default stagger 1), bit 8 = sum the partial sums in a second launch. */
+ * 1 + K-walk stagger of neighbouring column tiles (0 = default stagger 1), bit 8 = sum the partial sums inside the launch (last workgroup of a tile to arrive) instead of in a second launch. */
 void eagle_debug_set_rows(int target_wg, int min_steps, int stages);
 
 #ifdef __cplusplus
