@@ -40,6 +40,7 @@ struct AttnDecArgs {
   float sqrt_hd;
   int split_keys;             // keys per partial record (64: attn_split_kernel; 512: attn_wide_kernel)
   bf16_t* q_roped;            // wide path: [B][AD_MAXM][H*hd] roped queries (behind the partial records in the workspace)
+  int gq;                     // wide path: query heads of one KV head packed into the 16 MFMA columns of a workgroup (1, 2 or 4)
 };
 
 // workspace record per (b, h, split): [AD_MAXM][AD_MAXHD] fp32 O~  then [AD_MAXM][2] fp32 (m, l)
@@ -368,6 +369,9 @@ __global__ __launch_bounds__(2 * AD_MAXHD) void attn_combine_kernel(AttnDecArgs 
 //            read back TRANSPOSED (ds_read_b64_tr_b16) as the A operand of O^T += V^T . P^T on MFMA,
 // no workgroup barrier inside the loop; the four partial states merge once through LDS into one partial record per
 // 512 keys (an eighth of the records the combine pass has to read).
+// Grouped-query attention: a tree step has 1 or 4 query rows per request, so the 16 MFMA columns of a workgroup carry the
+// queries of `gq` heads that share one KV head (column = head-in-group * (16 / gq) + query): the group's K and V rows are
+// read once instead of once per query head, and a quarter of the workgroups do the same MFMA work.
 #define AW_TK 32
 #define AW_SPLIT 512
 typedef __attribute__((ext_vector_type(4))) short aw_s4;
@@ -423,14 +427,15 @@ __global__ __launch_bounds__(256) void attn_rope_append_kernel(AttnDecArgs p) {
   }
 }
 
-// grid (max_splits, H, B); hd = 128.  Reads q from q_roped and every key / value row (this call's included) from the cache.
+// grid (max_splits, H / gq, B); hd = 128.  Reads q from q_roped and every key / value row (this call's included) from the cache.
 __global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[4][2][AW_TK * 256];      // per wave: two V tiles; reused for the merge
   __shared__ float wm[4][AD_MAXM], wl[4][AD_MAXM];
-  const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int split = blockIdx.x, h0 = blockIdx.y * p.gq, b = blockIdx.z;
   const int M = p.M, hd = 128;
-  const int rep = p.H / p.HK, hk = h / rep;
+  const int rep = p.H / p.HK, hk = h0 / rep;             // gq divides rep: the group's heads share this KV head
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g = lane >> 4;
+  const int mq = 16 / p.gq;                              // MFMA columns per head
   const int past = p.past_len[b] + p.past_off;
   const int total = past + M;
   if (past < 0 || total > p.cap || (total + AW_SPLIT - 1) / AW_SPLIT > p.max_splits) return;   // flagged by the pre-pass
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p)
   const uint8_t* tm = p.tree_mask ? p.tree_mask + (int64_t)b * p.tm_bstride : nullptr;
   const uint8_t* pm = p.pad_mask ? p.pad_mask + (int64_t)b * p.pm_stride : nullptr;
   const int tree0 = total - p.T;
-  const int m = r16;                         // this lane's query (MFMA column)
+  const int m = r16 % mq, h = h0 + r16 / mq;  // this lane's MFMA column: query m of head h
 
   bf16x8 qf[4];
   {
@@ -561,26 +566,31 @@ __global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p)
   lrun += __shfl_xor(lrun, 16, 64);
   lrun += __shfl_xor(lrun, 32, 64);
   __syncthreads();                                                    // every wave is done with its V buffers
-  float* ow = reinterpret_cast<float*>(&lds[wave][0][0]);             // [16 queries][128 d] fp32 = 8 KB
+  float* ow = reinterpret_cast<float*>(&lds[wave][0][0]);             // [16 columns][128 d] fp32 = 8 KB
 #pragma unroll
-  for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(ow + m * 128 + 16 * dt + 4 * g) = o[dt];
-  if (g == 0) { wm[wave][m] = mrun; wl[wave][m] = lrun; }
+  for (int dt = 0; dt < 8; ++dt) *reinterpret_cast<f32x4*>(ow + r16 * 128 + 16 * dt + 4 * g) = o[dt];
+  if (g == 0) { wm[wave][r16] = mrun; wl[wave][r16] = lrun; }
   __syncthreads();
-  float* rec = p.ws + ((int64_t)(b * p.H + h) * p.max_splits + split) * AD_REC;
-  for (int i = t; i < M * 128; i += AD_THREADS) {
-    const int mm = i >> 7, d = i & 127;
-    float mx = fmaxf(fmaxf(wm[0][mm], wm[1][mm]), fmaxf(wm[2][mm], wm[3][mm]));
+  for (int i = t; i < 16 * 128; i += AD_THREADS) {
+    const int c = i >> 7, d = i & 127;                                // column c = query mm of head h0 + c / mq
+    const int mm = c % mq;
+    if (mm >= M) continue;
+    float mx = fmaxf(fmaxf(wm[0][c], wm[1][c]), fmaxf(wm[2][c], wm[3][c]));
     float acc = 0.f, l = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const float sc = (wm[w][mm] > -INFINITY) ? __expf(wm[w][mm] - mx) : 0.f;
-      acc += sc * reinterpret_cast<const float*>(&lds[w][0][0])[mm * 128 + d];
-      l += sc * wl[w][mm];
+      const float sc = (wm[w][c] > -INFINITY) ? __expf(wm[w][c] - mx) : 0.f;
+      acc += sc * reinterpret_cast<const float*>(&lds[w][0][0])[c * 128 + d];
+      l += sc * wl[w][c];
     }
+    float* rec = p.ws + ((int64_t)(b * p.H + h0 + c / mq) * p.max_splits + split) * AD_REC;
     rec[mm * AD_MAXHD + d] = acc;
     if (d == 0) { rec[AD_MAXM * AD_MAXHD + 2 * mm] = mx; rec[AD_MAXM * AD_MAXHD + 2 * mm + 1] = l; }
   }
 }
+
+static int g_attn_gq_off = 0;    // diagnostics (tests): 1 = one query head per workgroup of the wide-batch kernel
+extern "C" void eagle_debug_set_attn(int no_head_packing) { g_attn_gq_off = no_head_packing; }
 
 extern "C" int64_t eagle_attn_decode_workspace_bytes(int B, int H, int max_kv) {
   return (int64_t)B * H * ((max_kv + AD_CH - 1) / AD_CH) * AD_REC * sizeof(float)      // partial records (64-key form: the larger)
@@ -620,6 +630,7 @@ extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const 
                reinterpret_cast<uintptr_t>(kcache) | reinterpret_cast<uintptr_t>(vcache)) & 15) == 0);
   a.split_keys = AD_CH;
   a.q_roped = nullptr;
+  a.gq = 1;
   // wide batches: enough (request, head) pairs to fill the chip without 64-key workgroups
   if (hd == 128 && a.vec16 && (int64_t)B * H >= 256) {
     a.split_keys = AW_SPLIT;
@@ -630,7 +641,10 @@ extern "C" int eagle_tree_attention_bf16(const void* qkv, int64_t ld_qkv, const 
     hipLaunchKernelGGL(attn_rope_append_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, a);
     int rc = eagle_check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(attn_wide_kernel, dim3(a.max_splits, H, B), dim3(AD_THREADS), 0, stream, a);
+    const int grp = H / HK;                        // query heads per KV head
+    a.gq = (M <= 4 && grp % 4 == 0) ? 4 : (M <= 8 && grp % 2 == 0) ? 2 : 1;
+    if (g_attn_gq_off) a.gq = 1;
+    hipLaunchKernelGGL(attn_wide_kernel, dim3(a.max_splits, H / a.gq, B), dim3(AD_THREADS), 0, stream, a);
     rc = eagle_check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(attn_combine_kernel, dim3(H, B, (M + 1) / 2), dim3(2 * AD_MAXHD), 0, stream, a);

@@ -313,7 +313,8 @@ def test_single_token_prompt_and_batch_of_one_ragged():
     b.check_errors()
 
 
-@pytest.mark.parametrize("M,HK,use_tree", [(1, 32, False), (4, 32, True), (6, 32, False), (8, 8, True), (16, 32, False)])
+@pytest.mark.parametrize("M,HK,use_tree", [(1, 32, False), (4, 32, True), (6, 32, False), (8, 8, True), (16, 32, False),
+                                           (1, 8, False), (4, 8, True), (3, 16, True), (6, 16, False)])   # grouped-query: 4 / 2 heads per workgroup
 def test_wide_batch_attention_matches_the_per_request_kernel(M, HK, use_tree):
     """The wide-batch attention (RoPE/append pre-pass + 512-key workgroups with P.V on MFMA, chosen when B*H >= 256)
     against the 64-key split kernel run request by request (B*H < 256), which the oracle fixtures pin: same cache
