@@ -30,6 +30,7 @@ struct SkinnyArgs {
   bf16_t* out; int64_t ldo;
   int M, N, K;
   bool nt;                                               // host-side only: stream W with non-temporal loads
+  int rot;                                               // keepx: neighbouring blocks walk their K super-steps from staggered starts
 };
 
 template <int RT, int MT, int EPI>
@@ -447,9 +448,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   const bool do_norm = p.norm_eps > 0.f;
   const bool mvalid = r16 < p.M;
 
+  // Neighbouring blocks take their NI super-steps in rotated order: side by side they then read different 2 KB column
+  // groups of the weight rows instead of marching through the same HBM channels in step (registers stay statically
+  // indexed by `it`; only the addresses rotate).
+  static_assert((NI & (NI - 1)) == 0, "rotation masks with NI - 1");
+  const int rot = p.rot ? (blockIdx.x & (NI - 1)) : 0;
   bf16x8 a[S][4][RT];
   auto load_w = [&](bf16x8 (&st)[4][RT], int ts, int it) {
-    const int kb = (wave + SK_WAVES * it) << 7;
+    const int kb = (wave + SK_WAVES * ((it + rot) & (NI - 1))) << 7;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
       int n = row_lo + ts * RPS + ((EPI == EPI_SILU_MUL) ? (t >> 1) : t) * 16 + r16;
@@ -482,7 +488,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   for (int it = 0; it < NI; ++it)
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int k = ((wave + SK_WAVES * it) << 7) + s * 32;
+      const int k = ((wave + SK_WAVES * ((it + rot) & (NI - 1))) << 7) + s * 32;
       xk[it][s] = *reinterpret_cast<const bf16x8*>(((k < p.K0) ? xa : xb) + k);
     }
   float rstd = 1.f;
@@ -574,12 +580,14 @@ static int g_sk_keepx_stages = 2;   // register stages of the keepx kernel (2 or
 static int g_sk_keepx_bpc = 1;      // keepx workgroups per CU
 static int g_sk_keepx_rt = 0;       // 0: by shape; 1 / 2: forced 16-row weight tiles per tile-step (EPI_LINEAR)
 static int g_sk_silu_tile = 0;      // 1: SiLU*up projection of <= 16 rows on the tile kernel
+static int g_sk_rot = 1;            // keepx: staggered K walk of neighbouring blocks (bit 15 of the variant word turns it off)
 extern "C" void eagle_debug_set_skinny_variant(int v, int blocks_per_cu, int min_rows) {
   g_skinny_variant = v & 15;                       // bits 4-7: keepx register stages, bits 8-11: keepx blocks per CU
   if ((v >> 4) & 15) g_sk_keepx_stages = (v >> 4) & 15;
   if ((v >> 8) & 15) g_sk_keepx_bpc = (v >> 8) & 15;
   g_sk_keepx_rt = (v >> 12) & 3;
   g_sk_silu_tile = (v >> 14) & 1;
+  g_sk_rot = ((v >> 15) & 1) ? 0 : 1;
   if (blocks_per_cu > 0) g_sk_blocks_per_cu = blocks_per_cu;
   if (min_rows > 0) g_sk_min_rows = min_rows;
 }
@@ -685,7 +693,7 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     a.W = (const bf16_t*)W; a.W2 = (const bf16_t*)W2; a.bias = (const bf16_t*)bias;
     a.res = res ? (const bf16_t*)res + (int64_t)m0 * ldr : nullptr; a.ldr = ldr;
     a.out = (bf16_t*)out + (int64_t)m0 * ldo; a.ldo = ldo;
-    a.M = mc; a.N = N; a.K = K; a.nt = !keep_resident;
+    a.M = mc; a.N = N; a.K = K; a.nt = !keep_resident; a.rot = g_sk_rot;
     int rc;
     const int var = skinny_variant();   // 3 = per-shape choice (measured); 0/1/2 force one kernel family
     const bool big = (epi == EPI_SILU_MUL) || N >= 8192;
