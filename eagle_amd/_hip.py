@@ -83,6 +83,7 @@ SIGNATURES = {
     "eagle_debug_set_skinny_variant": (None, [I, I, I]),
     "eagle_debug_set_rows": (None, [I, I, I]),
     "eagle_debug_set_attn": (None, [I]),
+    "eagle_debug_set_topk": (None, [I]),
 }
 
 _lib = None

@@ -242,6 +242,106 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
   }
 }
 
+// ---- one launch for small vocabularies (bf16, <= 64 wave chunks: V <= 65536) ----
+// One 16-wave workgroup per row: wave w selects the k best of its CPW wave chunks {w, w+16, ...} in ONE selection (keys =
+// 16-bit monotone value | 12-bit slot among the wave's CPW*1024 logits, ordered so that the lowest global index wins a
+// tie: the wave's chunks are taken in ascending order), the 16 x k survivors go through LDS and wave 0 merges them -- the
+// same total order of (value, index) as the two-launch form, so the same result, in two selection passes instead of
+// three and without the second launch (a dependent small kernel costs ~5 us on the draft cycle: six top-k calls a cycle).
+#define TK_FUSED_WAVES 16
+#define TK_FUSED_MAXWC 64
+template <int CPW>
+__global__ __launch_bounds__(TK_FUSED_WAVES * 64) void topk_fused_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int V, int k, int nwc,
+                                                                            int64_t* __restrict__ out_idx, bf16_t* __restrict__ out_val,
+                                                                            const int64_t* __restrict__ block_index, int64_t block_rows,
+                                                                            int out_group, int64_t out_gstride) {
+  __shared__ unsigned long long surv[TK_FUSED_WAVES * TK_MAXK];
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (block_index) x += *block_index * block_rows * ld;
+  const bf16_t* xr = x + (int64_t)row * ld;
+  const bool al = ((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  constexpr int NKEY = CPW * TK_PER_LANE;
+  constexpr uint32_t SLOTS = CPW * TK_WCHUNK;                        // <= 4096: 12 bits
+  uint32_t key[NKEY];
+#pragma unroll
+  for (int c = 0; c < CPW; ++c) {
+    const int wc = wave + c * TK_FUSED_WAVES;
+    const int base = wc * TK_WCHUNK + lane * TK_PER_LANE;
+    const uint32_t slot0 = (uint32_t)(c * TK_WCHUNK + lane * TK_PER_LANE);   // ascending with the global index inside a wave
+    if (wc < nwc && al && base + TK_PER_LANE <= V) {
+      const uint4 a = *reinterpret_cast<const uint4*>(xr + base);
+      const uint4 b = *reinterpret_cast<const uint4*>(xr + base + 8);
+      const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        key[c * TK_PER_LANE + 2 * i] = (mono_bf16((bf16_t)(w[i] & 0xffff)) << 16) | (SLOTS - 1 - (slot0 + 2 * i));
+        key[c * TK_PER_LANE + 2 * i + 1] = (mono_bf16((bf16_t)(w[i] >> 16)) << 16) | (SLOTS - 1 - (slot0 + 2 * i + 1));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TK_PER_LANE; ++i) {
+        const int idx = base + i;
+        key[c * TK_PER_LANE + i] = (wc < nwc && idx < V) ? ((mono_bf16(xr[idx]) << 16) | (SLOTS - 1 - (slot0 + i))) : 0u;
+      }
+    }
+  }
+  uint32_t best = 0;
+#pragma unroll
+  for (int i = 0; i < NKEY; ++i) best = key[i] > best ? key[i] : best;
+  for (int r = 0; r < k; ++r) {
+    const uint32_t bm = wave_umax(best);
+    if (lane == 0) {
+      unsigned long long o = 0;
+      if (bm) {
+        const uint32_t slot = SLOTS - 1 - (bm & 0xffffu);
+        const uint32_t gidx = (uint32_t)((wave + (slot >> 10) * TK_FUSED_WAVES) * TK_WCHUNK) + (slot & (TK_WCHUNK - 1));
+        o = ((unsigned long long)(bm & 0xffff0000u) << 32) | (unsigned long long)(0xffffffffu - gidx);
+      }
+      surv[wave * TK_MAXK + r] = o;
+    }
+    if (bm != 0 && best == bm) {
+      best = 0;
+#pragma unroll
+      for (int i = 0; i < NKEY; ++i) {
+        if (key[i] == bm) key[i] = 0;
+        best = key[i] > best ? key[i] : best;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  unsigned long long key2[4];                                        // 16 x k <= 256 survivors: four per lane
+  unsigned long long best2 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    key2[i] = c < TK_FUSED_WAVES * k ? surv[(c / k) * TK_MAXK + (c % k)] : 0ull;
+    best2 = key2[i] > best2 ? key2[i] : best2;
+  }
+  unsigned long long won = 0;
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long bm = wave_umax64(best2);
+    if (lane == r) won = bm;
+    if (bm != 0 && best2 == bm) {
+      best2 = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (key2[i] == bm) key2[i] = 0;
+        best2 = key2[i] > best2 ? key2[i] : best2;
+      }
+    }
+  }
+  if (lane < k) {
+    const int64_t idx = won ? (int64_t)(0xffffffffu - (uint32_t)(won & 0xffffffffu)) : -1;
+    const int64_t opos = out_group ? (int64_t)(row / out_group) * out_gstride + (int64_t)(row % out_group) * k : (int64_t)row * k;
+    out_idx[opos + lane] = idx;
+    if (out_val) out_val[opos + lane] = idx >= 0 ? xr[idx] : (bf16_t)0;
+  }
+}
+
+static int g_topk_two_stage = 0;     // diagnostics (tests): 1 = always the two-launch form, 2 = the one-launch form wherever legal
+extern "C" void eagle_debug_set_topk(int two_stage) { g_topk_two_stage = two_stage; }
+
 extern "C" int64_t eagle_topk_workspace_bytes(int rows, int V, int k) {
   const int64_t nwc = (V + TK_WCHUNK - 1) / TK_WCHUNK;
   return (int64_t)rows * nwc * (k + 1) * 8;     // k candidates + one (max, sum-exp) partial per wave chunk
@@ -258,7 +358,16 @@ static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int 
   unsigned long long* cand = (unsigned long long*)workspace;
   float2* part = lse_out ? reinterpret_cast<float2*>(cand + (int64_t)rows * nwc * k) : nullptr;
   dim3 g1((nwc + 3) / 4, rows);
-  if (dtype == 0 && lse_out) {
+  // one launch where it is the faster form (measured in the batch-1 draft cycle, V = 32000: k = 1 7.6 us against 4.5 + 4.5;
+  // k = 10 14.3 us against 5.8 + 6.3 -- ten serial selection rounds on ONE workgroup cost more than the launch they save)
+  if (dtype == 0 && !lse_out && nwc <= TK_FUSED_MAXWC && (k <= 2 || g_topk_two_stage == 2) && g_topk_two_stage != 1) {
+#define TK_FUSED_LAUNCH(CPW) hipLaunchKernelGGL(topk_fused_bf16_kernel<CPW>, dim3(rows), dim3(TK_FUSED_WAVES * 64), 0, stream, \
+    (const bf16_t*)logits, ld, V, k, nwc, out_idx, (bf16_t*)out_val, block_index, block_rows, out_group, out_gstride)
+    if (nwc <= TK_FUSED_WAVES) TK_FUSED_LAUNCH(1);
+    else if (nwc <= 2 * TK_FUSED_WAVES) TK_FUSED_LAUNCH(2);
+    else TK_FUSED_LAUNCH(4);
+#undef TK_FUSED_LAUNCH
+  } else if (dtype == 0 && lse_out) {
     hipLaunchKernelGGL(topk_stage1_bf16_kernel<true>, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand,
                        block_index, block_rows, part);
     hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, true>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,

@@ -373,6 +373,10 @@ void eagle_debug_set_skinny_variant(int variant, int blocks_per_cu, int min_rows
 /* eagle_tree_attention_bf16, wide-batch kernel: 1 = one query head per workgroup (no packing of the query heads that
  * share a KV head into one workgroup's MFMA columns); 0 = default. */
 void eagle_debug_set_attn(int no_head_packing);
+/* eagle_topk_vocab*: 1 = always the two-launch form (candidates per 1024 logits, then the merge); 2 = the one-launch form
+ * (a 16-wave workgroup per row, candidates in LDS) for every bf16 call of up to 65536 columns; 0 = default: one launch
+ * for k <= 2 (the greedy argmax), two otherwise. */
+void eagle_debug_set_topk(int two_stage);
 /* eagle_gemm_rows_bf16: target_wg > 0 = workgroups the K split aims for (0 = by shape), min_steps = least 128-wide K
  * super-steps per slice (default 4); stages: bits 0-3 = 2 / 3 / 4 weight register stages (0 = default 3), bits 4-7 =
  * 1 + K-walk stagger of neighbouring column tiles (0 = default stagger 1), bit 8 = sum the partial sums inside the launch (last workgroup of a tile to arrive) instead of in a second launch. */

@@ -143,17 +143,23 @@ def test_rmsnorm(N, D):
 
 
 # ------------------------------------------------------------------ top-k (bit-exact ids)
-@pytest.mark.parametrize("rows,V", [(1, 32000), (8, 32000), (4, 151936), (3, 100), (2, 4097), (16, 9000)])
+@pytest.mark.parametrize("rows,V", [(1, 32000), (8, 32000), (4, 151936), (3, 100), (2, 4097), (16, 9000), (26, 65536), (5, 65537), (40, 33000)])
 @pytest.mark.parametrize("dtype", [BF, torch.float32])
 def test_topk_bit_exact(rows, V, dtype):
     from eagle_amd import ops
     g = torch.Generator().manual_seed(rows * 7 + V)
     x = (torch.randn(rows, V, generator=g) * 4).to(dtype)  # bf16 logits over a big vocab are full of ties
+    from eagle_amd._hip import lib
     ev, ei = ot.stable_topk(x, 10)
-    v, i = ops.topk(x.to(dev()), 10)
-    assert torch.equal(i.cpu(), ei), "top-k ids differ from the stable-sort oracle"
-    assert torch.equal(v.cpu(), ev)
-    assert torch.equal(ops.first_argmax(x.to(dev())).cpu(), ot.first_argmax(x))
+    try:
+        for two_stage in (0, 1, 2):   # default, the two-launch form, the one-launch form (bf16, V <= 65536): the same answer
+            lib().eagle_debug_set_topk(two_stage)
+            v, i = ops.topk(x.to(dev()), 10)
+            assert torch.equal(i.cpu(), ei), "top-k ids differ from the stable-sort oracle"
+            assert torch.equal(v.cpu(), ev)
+            assert torch.equal(ops.first_argmax(x.to(dev())).cpu(), ot.first_argmax(x))
+    finally:
+        lib().eagle_debug_set_topk(0)
 
 
 @pytest.mark.parametrize("rows,V", [(1, 32000), (8, 32000), (3, 151936), (5, 1000), (2, 4097)])
