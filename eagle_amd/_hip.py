@@ -36,6 +36,7 @@ SIGNATURES = {
     "eagle_gemm_nt_splitk_workspace_bytes": (L, [I, I, I]),
     "eagle_gemm_nt_splitk_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, I, P, P]),
     "eagle_gemm_tn_bf16": (I, [P, L, P, L, P, L, I, I, I, I, I, P]),
+    "eagle_gemm_nn_bf16": (I, [P, L, P, L, P, L, P, L, I, I, I, I, I, P]),
     "eagle_transpose_bf16": (I, [P, L, P, L, I, I, I, P]),
     "eagle_rmsnorm_fwd_bf16": (I, [P, P, P, P, I, I, F, P]),
     "eagle_rmsnorm_bwd_workspace_bytes": (L, [I, I]),

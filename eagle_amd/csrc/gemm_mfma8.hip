@@ -112,11 +112,14 @@ __device__ __forceinline__ void g8_stage_tn(const G8Src& s, int h, int kt, uint3
   }
 }
 typedef __attribute__((ext_vector_type(4))) short g8_s4;
+// NATURAL = false: lane group g holds k = 32s + {4g..4g+3, 16+4g..16+4g+3} (both operands K-major: any common k order will do);
+// NATURAL = true: k = 32s + 8g .. 8g+7, the order of a row-major operand's ds_read_b128 fragment (the other operand is row-major).
+template <bool NATURAL>
 __device__ __forceinline__ bf16x8 g8_tn_frag(const bf16_t* img, int tile, int s, int g, int tq, int tp) {
   const char* b = reinterpret_cast<const char*>(img);
-  const int r0 = 32 * s + 4 * g + tq;
+  const int r0 = 32 * s + (NATURAL ? 8 : 4) * g + tq, r1 = r0 + (NATURAL ? 4 : 16);
   const g8_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) g8_s4*)(b + g8_tn_off(r0, 2 * tile + (tp >> 1)) + 8 * (tp & 1)));
-  const g8_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) g8_s4*)(b + g8_tn_off(r0 + 16, 2 * tile + (tp >> 1)) + 8 * (tp & 1)));
+  const g8_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) g8_s4*)(b + g8_tn_off(r1, 2 * tile + (tp >> 1)) + 8 * (tp & 1)));
   union { struct { g8_s4 a, b; } q; bf16x8 v; } u;
   u.q.a = lo; u.q.b = hi;
   return u.v;
@@ -133,7 +136,8 @@ __device__ __forceinline__ void g8_stage(const G8Src& s, int h, int kt, bf16_t* 
   }
 }
 
-template <bool PINGPONG, int DBG = 0, bool TN = false>
+// TA / TB: operand A / B is stored K-major ([K, M] / [K, N]) and read through transposing LDS reads
+template <bool PINGPONG, int DBG = 0, bool TA = false, bool TB = false>
 __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   // ONE shared array (a second LDS object makes hipcc drain the DMA before every ds_read):
   // [buffer 2][A0, A1, B0, B1][128 x 64]  = 128 KB
@@ -169,14 +173,14 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   const int nk = min(p.kchunk, nk_all - kt0);       // K tiles of this slice (>= 1: launcher)
   auto kt_of = [&](int t) { return (DBG & 8) ? kt0 + (t & 1) : kt0 + (t < nk ? t : nk - 1); };
   auto hbuf = [&](int buf, int which) { return lds + (buf * 4 + which) * G8_HALF; };   // which: 0 A0, 1 A1, 2 B0, 3 B1
-  const G8Src srcA = TN ? g8_src_tn(p.A, p.lda, m0, p.K, tid) : g8_src(p.A, p.lda, p.M, m0, p.K, tid);
-  const G8Src srcB = TN ? g8_src_tn(p.B, p.ldb, n0, p.K, tid) : g8_src(p.B, p.ldb, p.N, n0, p.K, tid);
+  const G8Src srcA = TA ? g8_src_tn(p.A, p.lda, m0, p.K, tid) : g8_src(p.A, p.lda, p.M, m0, p.K, tid);
+  const G8Src srcB = TB ? g8_src_tn(p.B, p.ldb, n0, p.K, tid) : g8_src(p.B, p.ldb, p.N, n0, p.K, tid);
   const uint32_t ktA = (uint32_t)(p.lda * (G8_BK * 2)), ktB = (uint32_t)(p.ldb * (G8_BK * 2));   // TN: bytes per K tile of rows
   auto stage_a = [&](int h, int t) {
-    if (TN) g8_stage_tn(srcA, h, kt_of(t), ktA, hbuf(t & 1, h), tid); else g8_stage(srcA, h, kt_of(t), hbuf(t & 1, h), tid);
+    if (TA) g8_stage_tn(srcA, h, kt_of(t), ktA, hbuf(t & 1, h), tid); else g8_stage(srcA, h, kt_of(t), hbuf(t & 1, h), tid);
   };
   auto stage_b = [&](int h, int t) {
-    if (TN) g8_stage_tn(srcB, h, kt_of(t), ktB, hbuf(t & 1, 2 + h), tid); else g8_stage(srcB, h, kt_of(t), hbuf(t & 1, 2 + h), tid);
+    if (TB) g8_stage_tn(srcB, h, kt_of(t), ktB, hbuf(t & 1, 2 + h), tid); else g8_stage(srcB, h, kt_of(t), hbuf(t & 1, 2 + h), tid);
   };
   const int tq = (lane & 15) >> 2, tp = lane & 3;        // transposing-read lane geometry (TN)
 
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
       const int row = a_row0 + mh * 64 + i * 16;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        if (TN) af[i][s] = g8_tn_frag(la, mh * 4 + i, s, g, tq, tp);
+        if (TA) af[i][s] = g8_tn_frag<!TB>(la, mh * 4 + i, s, g, tq, tp);
         else af[i][s] = *reinterpret_cast<const bf16x8*>(la + row * G8_BK + (((4 * s + g) ^ (row & 7)) << 3));
       }
     }
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
       const int row = b_row0 + nh * 32 + j * 16;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        if (TN) bf[j][s] = g8_tn_frag(lb, (wc & 1) * 4 + nh * 2 + j, s, g, tq, tp);
+        if (TB) bf[j][s] = g8_tn_frag<!TA>(lb, (wc & 1) * 4 + nh * 2 + j, s, g, tq, tp);
         else bf[j][s] = *reinterpret_cast<const bf16x8*>(lb + row * G8_BK + (((4 * s + g) ^ (row & 7)) << 3));
       }
     }
@@ -511,6 +515,29 @@ extern "C" int eagle_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int
   a.ksplit = 1; a.kchunk = K / G8_BK; a.partial = nullptr;
   a.gm = a.tiles_m < 8 ? a.tiles_m : 8;
   a.tn = 1;
-  hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, true>), dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
+  hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, true, true>), dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
+  return eagle_check_launch();
+}
+
+// C[M,N] = A . B (+res) with B stored K-major: A [M, K] row-major (row stride lda), B [K, N] row-major (row stride ldb) --
+// the data gradients behind loss.backward() (eagle/train.py:126): dX[tokens, in] = dY[tokens, out] . W[out, in] reads the
+// weight as the state_dict stores it (no transposed copy per optimizer step).
+// N % 256 == 0, K % 64 == 0, K >= 128; lda / ldb % 8 == 0; 16-byte aligned bases; K * ldb * 2 < 4 GiB.
+extern "C" int eagle_gemm_nn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* res,
+                                  int64_t ldr, int M, int N, int K, int out_f32, int accumulate, hipStream_t stream) {
+  if (!A || !B || !C) return EAGLE_ERR_ARG;
+  if (M < 1 || N < 256 || (N & 255) || K < 2 * G8_BK || (K % G8_BK)) return EAGLE_ERR_SHAPE;
+  if ((lda & 7) || (ldb & 7) || lda < K || ldb < N || ldc < N || (res && ldr < N)) return EAGLE_ERR_SHAPE;
+  if (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B) | reinterpret_cast<uintptr_t>(C)) & 15)) return EAGLE_ERR_SHAPE;
+  if (lda > (1ll << 22) || (uint64_t)K * (uint64_t)ldb * 2ull > 0xffffffffull) return EAGLE_ERR_SHAPE;   // 32-bit byte offsets
+  Gemm8Args a;
+  a.A = (const bf16_t*)A; a.lda = lda; a.B = (const bf16_t*)B; a.ldb = ldb; a.C = C; a.ldc = ldc;
+  a.bias = nullptr; a.res = (const bf16_t*)res; a.ldr = ldr;
+  a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
+  a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = N / G8_BN;
+  a.ksplit = 1; a.kchunk = K / G8_BK; a.partial = nullptr;
+  a.gm = a.tiles_m < 8 ? a.tiles_m : 8;
+  a.tn = 1;
+  hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
   return eagle_check_launch();
 }

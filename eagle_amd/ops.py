@@ -187,6 +187,30 @@ def gemm_tn(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None
     return out
 
 
+def gemm_nn_ok(A: torch.Tensor, B: torch.Tensor) -> bool:
+    """Shapes eagle_gemm_nn_bf16 takes: A [M, K], B [K, N] row-major, N a multiple of 256, K a multiple of 64."""
+    M, K = A.shape
+    N = B.shape[1]
+    return (B.shape[0] == K and N % 256 == 0 and K % 64 == 0 and K >= 128 and A.stride(1) == 1 and B.stride(1) == 1
+            and A.stride(0) % 8 == 0 and B.stride(0) % 8 == 0 and K * B.stride(0) * 2 < 2 ** 32 and A.stride(0) <= 2 ** 22
+            and A.data_ptr() % 16 == 0 and B.data_ptr() % 16 == 0)
+
+
+def gemm_nn(A: torch.Tensor, B: torch.Tensor, res: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+            out_dtype=BF16) -> torch.Tensor:
+    """C[M,N] = A @ B (+res) for B stored K-major [K, N] (data gradients: the weight as the state_dict stores it)."""
+    _chk(A, "A"), _chk(B, "B")
+    M, K = A.shape
+    N = B.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    if out.dtype not in (BF16, torch.float32) or out.stride(1) != 1 or tuple(out.shape) != (M, N):
+        raise TypeError("gemm_nn: C must be bf16 or fp32 [M, N], row-major")
+    call("eagle_gemm_nn_bf16", ptr(A), A.stride(0), ptr(B), B.stride(0), ptr(out), out.stride(0), ptr(res),
+         (res.stride(0) if res is not None else 0), M, N, K, int(out.dtype == torch.float32), 0, stream())
+    return out
+
+
 def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None, pad_to: int = 1) -> torch.Tensor:
     """out[C, R_pad] = x[R,C]^T (bf16); R_pad = R rounded up to ``pad_to``, the extra columns zero."""
     _chk(x, "x")

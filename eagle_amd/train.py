@@ -163,24 +163,30 @@ def draft_bwd(W: LayerWeights, saved, dout: torch.Tensor, B: int, L: int, H: int
             ops.gemm_tn(dy, xin, out=out, accumulate=acc)
         else:
             ops.gemm_nt(T(dy), T(xin), out=out, accumulate=acc)
+    def dgrad(dy, key, w, res=None):
+        """dy[tokens, out_f] . w[out_f, in_f] (+res): the NN kernel reads the weight as it is stored (K-major B operand); other
+        shapes take the cached transposed copy."""
+        if ops.gemm_nn_ok(dy, w):
+            return ops.gemm_nn(dy, w, res=res)
+        return ops.gemm_nt(dy, tc.get(key, w), res=res)
     # down_proj: out = act . Wdown^T + h1
-    d_act = ops.gemm_nt(dout, tc.get("wdown", W.wdown))
+    d_act = dgrad(dout, "wdown", W.wdown)
     wgrad(dout, act, sink.wdown)
     ready("wdown")
     dgu = ops.silu_mul_bwd(gu, d_act)
     del d_act
-    dn = ops.gemm_nt(dgu, tc.get("wgu", W.wgu))
+    dn = dgrad(dgu, "wgu", W.wgu)
     wgrad(dgu, n, sink.wgu)
     ready("wgu")
     del dgu
     dh1, _ = ops.rmsnorm_bwd(dn, h1, W.wn, rstd, res=dout, dw=sink.wn, accumulate_dw=acc)   # + residual branch
     ready("wn")
-    d_attn = ops.gemm_nt(dh1, tc.get("wo", W.wo))
+    d_attn = dgrad(dh1, "wo", W.wo)
     wgrad(dh1, attn, sink.wo)
     ready("wo")
     dqkv = ops.attn_train_bwd(qkv, attn, d_attn, lse, B, L, H, hd)
     ops.rope_qk_(dqkv, cos, sin, L, 2 * H, hd, position_ids=position_ids, inverse=True)
-    dx = ops.gemm_nt(dqkv, tc.get("wqkv", W.wqkv), res=dh1)       # + residual branch of :385
+    dx = dgrad(dqkv, "wqkv", W.wqkv, res=dh1)                     # + residual branch of :385
     wgrad(dqkv, x, sink.wqkv)
     ready("wqkv")
     wgrad(dx, x0, sink.fc_w)

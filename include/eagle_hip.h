@@ -89,6 +89,12 @@ int eagle_gemm_nt_splitk_bf16(const void* A, int64_t lda, const void* B, int64_t
  * then transposes and calls eagle_gemm_nt_bf16).  C bf16 (out_f32 = 0) or fp32; accumulate != 0: C += result. */
 int eagle_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
                        int out_f32, int accumulate, eagle_stream_t stream);
+/* C[M,N] = A . B (+res[M,N]) with B stored K-major: A [M,K] row-major (row stride lda), B [K,N] row-major (row stride ldb).
+ * The data gradients behind loss.backward() (eagle/train.py:126): dX = dY . W reads the weight [out, in] as the state_dict
+ * stores it -- no transposed weight copy after each optimizer step.  N % 256 == 0, K % 64 == 0, K >= 128; lda, ldb % 8 == 0;
+ * 16-byte aligned bases; K * ldb * 2 < 4 GiB.  C bf16 (out_f32 = 0) or fp32; accumulate: C += . */
+int eagle_gemm_nn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* res,
+                       int64_t ldr, int M, int N, int K, int out_f32, int accumulate, eagle_stream_t stream);
 /* out[C,R_pad] = in[R,C]^T, bf16, columns [R, R_pad) zero-filled (R_pad < R: no padding): operand
  * preparation for the dgrad / wgrad GEMMs behind loss.backward() (eagle/train.py:126); the zero
  * padding lets a token count that is no multiple of 64 serve as the GEMM's K.  ldo >= R_pad. */

@@ -34,6 +34,10 @@ def gemm_tn_ok(A, B):
     return False            # the CPU stand-ins take the transpose + NT route
 
 
+def gemm_nn_ok(A, B):
+    return False
+
+
 def transpose(x, out=None, pad_to=1):
     R, C = x.shape
     Rp = (R + pad_to - 1) // pad_to * pad_to
@@ -236,7 +240,7 @@ def install(monkeypatch_setattr=None):
     g = globals()
     for name in ("gemm_nt", "transpose", "embed_concat", "rope_qk_", "attn_train_fwd", "attn_train_bwd", "rmsnorm", "rmsnorm_bwd",
                  "silu_mul", "silu_mul_bwd", "colsum", "adamw_", "grad_clip_coef", "clip_value_", "scale_", "add_f32_bf16",
-                 "ce_partial", "ce_combine", "ce_smoothl1_bwd", "rope_tables", "require_device", "gemm_tn_ok"):
+                 "ce_partial", "ce_combine", "ce_smoothl1_bwd", "rope_tables", "require_device", "gemm_tn_ok", "gemm_nn_ok"):
         if monkeypatch_setattr is not None:
             monkeypatch_setattr(ops, name, g[name])
         else:

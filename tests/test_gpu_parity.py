@@ -698,6 +698,27 @@ def test_gemm_nt_split_k(M, N, K, S):
     close(yf, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="split-k fp32")
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 4096), (300, 512, 256), (256, 12288, 4096), (1000, 256, 1536)])
+def test_gemm_nn_k_major_weight(M, N, K):
+    """eagle_gemm_nn_bf16 (the data gradients: dX = dY . W with W read as stored, through transposing LDS reads) against
+    the NT kernel on an explicitly transposed copy -- the k order inside an MFMA step differs, so agreement is to
+    2^-7 of the largest magnitude, not bit for bit -- and with the residual epilogue."""
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(BF).to(dev())
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(BF).to(dev())
+    r = torch.randn(M, N, generator=g).to(BF).to(dev())
+    assert ops.gemm_nn_ok(A, W)
+    ref = ops.gemm_nt(A, ops.transpose(W))
+    got = ops.gemm_nn(A, W)
+    assert float((got.float() - ref.float()).abs().max()) <= 2.0 ** -7 * float(ref.float().abs().max())
+    close(got, A.float() @ W.float(), what="gemm_nn vs fp32")
+    ref_r = ops.gemm_nt(A, ops.transpose(W), res=r)
+    got_r = ops.gemm_nn(A, W, res=r)
+    assert float((got_r.float() - ref_r.float()).abs().max()) <= 2.0 ** -7 * float(ref_r.float().abs().max())
+
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 4096), (4096, 12288, 2048), (256, 1024, 64 * 5)])
 def test_gemm_tn_k_major_operands(M, N, K):
     """C (+)= A^T . B with A [K, M], B [K, N] as they lie in memory (the weight-gradient GEMMs, no transpose pass): against
