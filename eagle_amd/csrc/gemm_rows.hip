@@ -1,4 +1,5 @@
-// Weight-streaming GEMM for decode batches of 17..128 rows (batch-32 tree steps: 32 x {1,4} rows per forward).
+// Weight-streaming GEMM for decode batches of 17..192 rows (batch-32 tree steps: 32 x {1,4} rows per forward; the catch-up
+// forward over the accepted tokens: 32 x <= 6).
 //
 //   out[M,N] = epilogue( x[M,K] . W[N,K]^T )        bf16 in, fp32 accumulate, same epilogues as gemm_skinny.hip
 //
@@ -25,6 +26,7 @@
 
 #define GR_NW 4                         // consumer waves per workgroup
 #define GR_COUNTER_BYTES 16384          // head of the workspace: one arrival counter per column tile (<= 4096 tiles split)
+#define GR_MAX_ROWS 192
 #define GR_EPI_LINEAR 0
 #define GR_EPI_SILU_MUL 1
 #define GR_KEEP_RESIDENT 0x100          // accepted and ignored: this path always streams W non-temporally
@@ -339,7 +341,7 @@ struct RowsPlan { int mt, tiles, ks, kchunk; };
 static RowsPlan gr_plan(int M, int N, int K, int epi) {
   RowsPlan pl;
   const int mt = (M + 15) / 16;
-  pl.mt = mt <= 2 ? 2 : mt <= 4 ? 4 : mt <= 6 ? 6 : 8;
+  pl.mt = mt <= 2 ? 2 : mt <= 4 ? 4 : mt <= 6 ? 6 : mt <= 8 ? 8 : 12;
   const int bn = (epi == GR_EPI_SILU_MUL) ? RowsGeom<2, GR_EPI_SILU_MUL>::BN : RowsGeom<2, GR_EPI_LINEAR>::BN;
   pl.tiles = (N + bn - 1) / bn;
   const int nj = K >> 7;
@@ -355,7 +357,7 @@ static RowsPlan gr_plan(int M, int N, int K, int epi) {
 
 extern "C" int64_t eagle_gemm_rows_workspace_bytes(int M, int N, int K, int epi) {
   epi &= ~GR_KEEP_RESIDENT;
-  if (M < 1 || M > 128 || N < 1 || K < 128 || (K & 127) || (epi != GR_EPI_LINEAR && epi != GR_EPI_SILU_MUL)) return 0;
+  if (M < 1 || M > GR_MAX_ROWS || N < 1 || K < 128 || (K & 127) || (epi != GR_EPI_LINEAR && epi != GR_EPI_SILU_MUL)) return 0;
   const RowsPlan pl = gr_plan(M, N, K, epi);
   if (pl.ks == 1) return 0;
   return GR_COUNTER_BYTES + (int64_t)pl.ks * pl.tiles * GR_NW * (pl.mt * 2) * 64 * 16;
@@ -363,7 +365,9 @@ extern "C" int64_t eagle_gemm_rows_workspace_bytes(int M, int N, int K, int epi)
 
 template <int MT, int EPI, int S>
 static int gr_launch_s(const RowsArgs& a, hipStream_t st) {
-  constexpr int XS = 4;      // x chunks in LDS: the loader runs 3 super-steps ahead (an L2 hit under a full HBM stream takes > 1 us)
+  // x chunks in LDS: the loader runs 3 super-steps ahead (an L2 hit under a full HBM stream takes > 1 us); 192 rows: 2 ahead
+  // (3 x 48 KB of the 160 KB)
+  constexpr int XS = MT > 8 ? 3 : 4;
   constexpr int NL = MT <= 2 ? 1 : MT <= 4 ? 2 : 4;
   hipLaunchKernelGGL((gemm_rows_stream_kernel<MT, 2, EPI, S, XS, NL>), dim3(a.tiles * a.ks), dim3((GR_NW + NL) * 64), 0, st, a);
   int rc = eagle_check_launch();
@@ -373,9 +377,12 @@ static int gr_launch_s(const RowsArgs& a, hipStream_t st) {
 }
 template <int MT, int EPI>
 static int gr_launch(const RowsArgs& a, hipStream_t st) {
+  if constexpr (MT > 8) return gr_launch_s<MT, EPI, 2>(a, st);     // 192 rows: 96 accumulator registers leave room for 2 stages
+  else {
   if (g_rows_stages == 2) return gr_launch_s<MT, EPI, 2>(a, st);
   if constexpr (MT <= 4) { if (g_rows_stages == 4) return gr_launch_s<MT, EPI, 4>(a, st); }
   return gr_launch_s<MT, EPI, 3>(a, st);
+  }
 }
 template <int EPI>
 static int gr_launch_mt(const RowsArgs& a, int mt, hipStream_t st) {
@@ -383,7 +390,8 @@ static int gr_launch_mt(const RowsArgs& a, int mt, hipStream_t st) {
     case 2: return gr_launch<2, EPI>(a, st);
     case 4: return gr_launch<4, EPI>(a, st);
     case 6: return gr_launch<6, EPI>(a, st);
-    default: return gr_launch<8, EPI>(a, st);
+    case 8: return gr_launch<8, EPI>(a, st);
+    default: return gr_launch<12, EPI>(a, st);
   }
 }
 
@@ -401,7 +409,7 @@ extern "C" int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t
   if (epi != GR_EPI_LINEAR && epi != GR_EPI_SILU_MUL) return EAGLE_ERR_ARG;
   if (ind0 && (!idx0 || ind_n < 1)) return EAGLE_ERR_ARG;
   if (epi == GR_EPI_SILU_MUL && (!W2 || bias || res)) return EAGLE_ERR_ARG;
-  if (M < 1 || M > 128 || N < 1 || K < 128 || (K & 127)) return EAGLE_ERR_SHAPE;
+  if (M < 1 || M > GR_MAX_ROWS || N < 1 || K < 128 || (K & 127)) return EAGLE_ERR_SHAPE;
   if (x1) { if (K0 <= 0 || K0 >= K || (K0 & 127) || (ld1 & 7) || !gr_al16(x1)) return EAGLE_ERR_SHAPE; }
   else K0 = K;
   if ((ld0 & 7) || (ldw & 7) || ldw < K || !gr_al16(x0) || !gr_al16(W) || (W2 && !gr_al16(W2))) return EAGLE_ERR_SHAPE;

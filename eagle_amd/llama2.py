@@ -147,7 +147,7 @@ class Llama2Model(nn.Module):
         self._rows_out: List[int] = []                   # most rows of each buffer ever handed out as a view
         self._packed = {}
         self._weight_epoch = 0                           # part of every derived-weight cache key
-        # forwards of rows_min .. 128 rows run on the row-batch weight stream (eagle_gemm_rows_bf16); below, on the
+        # forwards of rows_min .. 192 rows run on the row-batch weight stream (eagle_gemm_rows_bf16); below, on the
         # per-step weight-stream kernels.  Tests that compare a batch with per-request runs bit for bit set it to 1, so
         # that both sides sum K in the same order.
         self.rows_min = 17
@@ -317,7 +317,7 @@ class Llama2Model(nn.Module):
             # indirection of the weight-stream GEMM covers one 64-row pass)
             emb_idx = ops.tree_gather_ids(emb_idx, emb_ind, B=B, batch_stride=emb_bstride).reshape(-1)
             emb_ind, emb_bstride = None, 0
-        # decode batches (a batch of requests stepping through the tree together: 17..128 rows): every projection is one
+        # decode batches (a batch of requests stepping through the tree together: 17..192 rows): every projection is one
         # weight pass of the row-batch weight stream (W to registers, x through LDS, K split where the matrix is small)
         mid = self.rows_min <= M <= ops.ROWS_MAX and self.config.hidden_size % 128 == 0 and self.config.intermediate_size % 128 == 0 \
             and hid.dim() == 2 and hid.stride(1) == 1
@@ -370,7 +370,7 @@ class Llama2Model(nn.Module):
 
     def _forward_rows_mid(self, emb_idx, hid, hid_idx, M, B, q_len, pos, past_dev, max_kv, tmask, pad, caches,
                           past_host, past_off0, pos_off, pos_stride, emb_ind, emb_bstride, cos, sin):
-        """_forward_rows for 17..128 rows: the same chain on eagle_gemm_rows_bf16 (row gathers, the cat of fc, the residual
+        """_forward_rows for 17..192 rows: the same chain on eagle_gemm_rows_bf16 (row gathers, the cat of fc, the residual
         adds and SiLU*up all in the GEMM's loader / epilogue; the RMSNorms as their own small kernels)."""
         dev = hid.device
         H, HK, hd = self._dims()

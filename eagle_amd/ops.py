@@ -68,7 +68,7 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
     return out
 
 
-ROWS_MAX = 128   # rows one eagle_gemm_rows_bf16 call takes
+ROWS_MAX = 192   # rows one eagle_gemm_rows_bf16 call takes
 _rows_ws_cache = {}
 
 
@@ -89,7 +89,7 @@ def linear_rows(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] =
                 idx1: Optional[torch.Tensor] = None, M: Optional[int] = None,
                 out: Optional[torch.Tensor] = None, ind0: Optional[torch.Tensor] = None,
                 idx0_bstride: int = 0) -> torch.Tensor:
-    """linear_skinny's product for a decode batch of up to 128 rows in ONE weight pass (eagle_gemm_rows_bf16): W straight
+    """linear_skinny's product for a decode batch of up to 192 rows in ONE weight pass (eagle_gemm_rows_bf16): W straight
     to registers, x through LDS, K split over workgroups where the matrix has few column tiles.  W (and W2) [N, K] with
     any row stride that is a multiple of 8; K (and the cat boundary) multiples of 128."""
     _chk(x, "x"), _chk(W, "W")

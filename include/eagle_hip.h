@@ -48,7 +48,7 @@ int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int
                            const void* res, int64_t ldr, void* out, int64_t ldo,
                            int M, int N, int K, int epi, eagle_stream_t stream);
 
-/* The same product for decode BATCHES, 1 <= M <= 128 rows (a batch of requests stepping through the draft tree together:
+/* The same product for decode BATCHES, 1 <= M <= 192 rows (a batch of requests stepping through the draft tree together:
  * 32 requests x 1 or 4 tree rows): one weight pass for all rows.  Operands and epilogues as eagle_gemm_skinny_bf16
  * (no norm_eps: run eagle_rmsnorm_fwd_bf16 first); W [N, K] with row stride ldw (W2 too), K % 128 == 0, K0 % 128 == 0.
  * Few column tiles are cut along K; the fp32 partial sums go through `workspace`

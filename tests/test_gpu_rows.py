@@ -1,5 +1,5 @@
 """eagle_gemm_rows_bf16 (decode batches of up to 128 rows in one weight pass) against fp32 torch on the same inputs, through
-the C ABI: every row-tile count, split and unsplit K, both epilogues, gathered / concatenated / doubly indirected rows."""
+the C ABI: every row-tile count (2, 4, 6, 8, 12 tiles of 16 rows), split and unsplit K, both epilogues, gathered / concatenated / doubly indirected rows."""
 import pytest
 import torch
 
@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("M,N,K", [(17, 4096, 4096), (32, 4096, 4096), (33, 6144, 4096), (64, 4096, 8192), (84, 4096, 4096),
                                    (96, 4096, 12288), (128, 4096, 4096), (128, 24576, 4096), (128, 151936, 4096), (32, 151936, 4096),
-                                   (1, 128, 128), (20, 1000, 256), (128, 200, 384), (50, 72, 1024)])
+                                   (1, 128, 128), (20, 1000, 256), (128, 200, 384), (50, 72, 1024), (192, 4096, 4096), (150, 12288, 4096), (161, 4096, 8192),
+                                   (192, 600, 256)])
 def test_gemm_rows_linear(M, N, K):
     from eagle_amd import ops
     g = torch.Generator().manual_seed(M * 131 + N + K)
@@ -24,7 +25,7 @@ def test_gemm_rows_linear(M, N, K):
     close(ops.linear_rows(x, W, bias=b, res=r), ref2, what="rows bias+res")
 
 
-@pytest.mark.parametrize("M,I,K", [(32, 12288, 4096), (128, 12288, 4096), (84, 11008, 4096), (24, 200, 128), (100, 64, 512)])
+@pytest.mark.parametrize("M,I,K", [(32, 12288, 4096), (128, 12288, 4096), (84, 11008, 4096), (24, 200, 128), (100, 64, 512), (192, 12288, 4096), (130, 96, 256)])
 def test_gemm_rows_silu_mul(M, I, K):
     from eagle_amd import ops
     g = torch.Generator().manual_seed(7 + M)
@@ -92,4 +93,4 @@ def test_gemm_rows_rejects_bad_shapes():
         ops.linear_rows(torch.zeros(2, 192, dtype=BF, device=dev()), W)       # K % 128 != 0
     W = torch.zeros(16, 256, dtype=BF, device=dev())
     with pytest.raises(HipKernelError):
-        ops.linear_rows(torch.zeros(129, 256, dtype=BF, device=dev()), W)     # more than 128 rows
+        ops.linear_rows(torch.zeros(193, 256, dtype=BF, device=dev()), W)     # more than 192 rows
