@@ -446,6 +446,7 @@ def main():
             torch.cuda.synchronize()
 
     from eagle_amd.speculative import EagleDrafter
+    from eagle_amd.train import all_reduce_           # gloo rehearsals stage device tensors through the host
 
     t_start = time.perf_counter()
 
@@ -478,11 +479,11 @@ def main():
         raise SystemExit(f"timed replay diverged from the recorded generation: {final} vs {rec_final}")
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_(t, dist.group.WORLD, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     acc = torch.tensor([accepted, a.steps], dtype=torch.float64, device=dev)   # tokens per verify = accept_len + 1
     if dist is not None:
-        dist.all_reduce(acc)
+        all_reduce_(acc, dist.group.WORLD)
     mean_accept = float(acc[0] / acc[1])
 
     out = {

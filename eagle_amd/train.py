@@ -94,6 +94,20 @@ def layer_weights(model) -> LayerWeights:
         wdown=m.down_proj.weight.detach(), eps=layer.post_attention_layernorm.variance_epsilon)
 
 
+def all_reduce_(t: torch.Tensor, group, op=None) -> None:
+    """dist.all_reduce in place.  Under gloo (CPU tests, and the rehearsal of N ranks on fewer GPUs) a device tensor goes
+    through host memory: gloo's own CUDA staging does not return on this image when the device has queued work or two
+    ranks share a GPU (tools/dp_rehearsal.py).  RCCL takes the device tensor as it is."""
+    import torch.distributed as dist
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        host = t.cpu()                       # orders behind everything queued on the current stream
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 class _TransposeCache:
     """W^T per weight, rebuilt when the weight's storage or version changes."""
 
@@ -449,7 +463,7 @@ class EagleTrainer:
         masks = [mb["loss_mask"].reshape(-1).to(torch.float32).contiguous() for mb in micro_batches]
         n_items = torch.stack([m.sum() for m in masks]).sum().reshape(1)
         if self.group is not None:
-            dist.all_reduce(n_items, group=self.group)                      # train.py:92-93
+            all_reduce_(n_items, self.group)                                # train.py:92-93
         num_items = float(n_items.item())
         if num_items == 0:                                                 # train_tp.py:77-79 skips; train.py:124 would divide by zero
             return {"skipped": True, "num_items": 0.0}
@@ -510,7 +524,7 @@ class EagleTrainer:
         self._optimizer_step()
         stats = self._sums.clone()
         if self.group is not None:
-            dist.all_reduce(stats, group=self.group)                        # train.py:137-148 as ONE reduce
+            all_reduce_(stats, self.group)                                  # train.py:137-148 as ONE reduce
         return {"sums": stats, "num_items": num_items, "lr": self.current_lr()}
 
     def _tc_versioned(self):
@@ -545,10 +559,8 @@ class EagleTrainer:
                     if dist.get_backend(self.group) != "gloo":
                         works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.AVG, group=self.group, async_op=True))
                     else:
-                        if self.grad.is_cuda:
-                            torch.cuda.synchronize()
                         for a in range(lo, hi, 16 * 1024 * 1024):
-                            dist.all_reduce(self.grad[a:min(a + 16 * 1024 * 1024, hi)], op=dist.ReduceOp.AVG, group=self.group)
+                            all_reduce_(self.grad[a:min(a + 16 * 1024 * 1024, hi)], self.group, op=dist.ReduceOp.AVG)
         return on_ready
 
     def _optimizer_step(self):
@@ -617,5 +629,5 @@ class ShardedLmHeadLoss:
         # (replicated) smooth-L1 part is added once
         part = ops.gemm_nt(dlog, self.wt, out_dtype=torch.float32)
         if self.world > 1:
-            dist.all_reduce(part, group=self.group)
+            all_reduce_(part, self.group)
         return sums, ops.add_f32_bf16(part, dpv)

@@ -135,7 +135,8 @@ def train_tokens_per_s(dev, rank: int, world: int, dist, steps: int = 6, warmup:
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if group is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        from .train import all_reduce_
+        all_reduce_(t, group, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     sums = out["sums"].cpu()
     toks = world * ga * MB * L * steps
