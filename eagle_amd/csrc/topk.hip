@@ -178,7 +178,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_f32_kernel(const float
   }
 }
 
-template <typename T, bool LSE>
+// K32 (every candidate index < 65536): the merge runs on 32-bit keys (16-bit monotone value | 0xffff - index), one DPP
+// reduction per selection round instead of the two of a 64-bit key.
+template <typename T, bool LSE, bool K32 = false>
 __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
                                                                 const T* __restrict__ x, int64_t ld,
                                                                 int64_t* __restrict__ out_idx, T* __restrict__ out_val,
@@ -188,6 +190,30 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
   __shared__ unsigned long long surv[4 * TK_MAXK];
   if (block_index) x += *block_index * block_rows * ld;
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (K32) {
+    // candidate c = value16 << 48 | (0xffffffff - index): with index < 65536 the low half is 0xffff0000 | (0xffff - index)
+    uint32_t key[TK_CM];
+    uint32_t best = 0;
+#pragma unroll
+    for (int i = 0; i < TK_CM; ++i) {
+      const int c = t + i * TK_THREADS;
+      const unsigned long long v = c < ncand ? cand[(int64_t)row * ncand + c] : 0ull;
+      key[i] = v ? ((uint32_t)(v >> 32) | ((uint32_t)v & 0xffffu)) : 0u;
+      best = key[i] > best ? key[i] : best;
+    }
+    for (int r = 0; r < k; ++r) {
+      const uint32_t bm = wave_umax(best);
+      if (lane == 0) surv[wave * TK_MAXK + r] = bm ? (((unsigned long long)(bm & 0xffff0000u) << 32) | 0xffff0000ull | (bm & 0xffffu)) : 0ull;
+      if (bm != 0 && best == bm) {
+        best = 0;
+#pragma unroll
+        for (int i = 0; i < TK_CM; ++i) {
+          if (key[i] == bm) key[i] = 0;
+          best = key[i] > best ? key[i] : best;
+        }
+      }
+    }
+  } else {
   unsigned long long key[TK_CM];
 #pragma unroll
   for (int i = 0; i < TK_CM; ++i) {
@@ -209,6 +235,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
       }
     }
   }
+  }
   __syncthreads();
   if (LSE && wave == 1) {                  // row log-sum-exp from the stage-1 partials, beside wave 0's final merge
     float m = -INFINITY, sm = 0.f;
@@ -227,10 +254,19 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
   unsigned long long mine = 0;
   if (lane < 4 * k) mine = surv[(lane / k) * TK_MAXK + (lane % k)];
   unsigned long long won = 0;                  // lane r keeps the r-th winner: the k value loads and
-  for (int r = 0; r < k; ++r) {                // stores below then go out together, not one per round
-    const unsigned long long bm = wave_umax64(mine);
-    if (lane == r) won = bm;
-    if (bm != 0 && mine == bm) mine = 0;
+  if (K32) {                                   // stores below then go out together, not one per round
+    uint32_t m32 = mine ? ((uint32_t)(mine >> 32) | ((uint32_t)mine & 0xffffu)) : 0u;
+    for (int r = 0; r < k; ++r) {
+      const uint32_t bm = wave_umax(m32);
+      if (lane == r) won = bm ? (0xffff0000ull | (bm & 0xffffu)) : 0ull;      // only the low (index) half is read below
+      if (bm != 0 && m32 == bm) m32 = 0;
+    }
+  } else {
+    for (int r = 0; r < k; ++r) {
+      const unsigned long long bm = wave_umax64(mine);
+      if (lane == r) won = bm;
+      if (bm != 0 && mine == bm) mine = 0;
+    }
   }
   if (lane < k) {
     // fewer than k entries can only happen when V < k; emit index -1 then
@@ -375,8 +411,12 @@ static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int 
   } else if (dtype == 0) {
     hipLaunchKernelGGL(topk_stage1_bf16_kernel<false>, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand,
                        block_index, block_rows, part);
-    hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
-                       (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
+    if (V <= 65536)
+      hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false, true>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+                         (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
+    else
+      hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+                         (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
   } else if (dtype == 1 && !lse_out) {
     hipLaunchKernelGGL(topk_stage1_f32_kernel, g1, dim3(TK_THREADS), 0, stream, (const float*)logits, ld, V, k, nwc, cand, block_index, block_rows);
     hipLaunchKernelGGL((topk_stage2_kernel<float, false>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
