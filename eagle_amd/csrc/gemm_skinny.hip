@@ -432,13 +432,15 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
 // for all of the block's rows (no per-tile-step re-read of x through L2: at 8 tokens that re-read
 // is half as many bytes again as the weight stream), the RMSNorm row statistics are computed once,
 // and the super-step loop is fully unrolled: stage parity, x fragment and refill target are static.
-template <int RT, int EPI, int NI, bool NT, int S = 2>
+// MT = 16-row activation tiles whose fragments stay in registers (1: <= 16 rows, every tree step of one request; 2: <= 32
+// rows, a 32-request batch at one row each -- each weight fragment then feeds two MFMAs instead of one).
+template <int RT, int EPI, int NI, bool NT, int S = 2, int MT = 1>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
   static_assert(NI % S == 0, "S register stages rotate through the NI super-steps of a tile-step");
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;
   constexpr int RPS = RTW * 16;
-  __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][RT][64][4];
-  __shared__ float red_ss[SK_WAVES][16];
+  __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][MT * RT][64][4];
+  __shared__ float red_ss[SK_WAVES][MT * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int row_lo = blockIdx.x * rows_per_block;
@@ -446,7 +448,6 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   if (row_lo >= row_hi) return;
   const int n_ts = (row_hi - row_lo + RPS - 1) / RPS;
   const bool do_norm = p.norm_eps > 0.f;
-  const bool mvalid = r16 < p.M;
 
   // Neighbouring blocks take their NI super-steps in rotated order: side by side they then read different 2 KB column
   // groups of the weight rows instead of marching through the same HBM channels in step (registers stay statically
@@ -470,102 +471,122 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
 #pragma unroll
   for (int st = 0; st < S; ++st) load_w(a[st], 0, st);
   // activation rows (possibly gathered: two dependent index loads) -> registers, once
-  const bf16_t* xa;
-  const bf16_t* xb;
-  {
-    int64_t ra = 0, rb = 0;
-    if (mvalid) {
-      const int m = r16;
-      if (p.ind0) ra = p.idx0[(int64_t)(m / p.ind_n) * p.idx0_bstride + p.ind0[m % p.ind_n]];
-      else ra = p.idx0 ? p.idx0[m] : m;
-      rb = p.idx1 ? p.idx1[m] : m;
-    }
-    xa = p.x0 + ra * p.ld0 + 8 * g;
-    xb = p.x1 ? (p.x1 + rb * p.ld1 + 8 * g - p.K0) : xa;
-  }
-  bf16x8 xk[NI][4];
+  bf16x8 xk[MT][NI][4];
+  float rstd[MT];
 #pragma unroll
-  for (int it = 0; it < NI; ++it)
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int k = ((wave + SK_WAVES * ((it + rot) & (NI - 1))) << 7) + s * 32;
-      xk[it][s] = *reinterpret_cast<const bf16x8*>(((k < p.K0) ? xa : xb) + k);
+  for (int mt = 0; mt < MT; ++mt) {
+    const bf16_t* xa;
+    const bf16_t* xb;
+    {
+      int64_t ra = 0, rb = 0;
+      const int m = mt * 16 + r16;
+      if (m < p.M) {
+        if (p.ind0) ra = p.idx0[(int64_t)(m / p.ind_n) * p.idx0_bstride + p.ind0[m % p.ind_n]];
+        else ra = p.idx0 ? p.idx0[m] : m;
+        rb = p.idx1 ? p.idx1[m] : m;
+      }
+      xa = p.x0 + ra * p.ld0 + 8 * g;
+      xb = p.x1 ? (p.x1 + rb * p.ld1 + 8 * g - p.K0) : xa;
     }
-  float rstd = 1.f;
-  if (do_norm) {
-    float ssq = 0.f;
 #pragma unroll
     for (int it = 0; it < NI; ++it)
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
+        const int k = ((wave + SK_WAVES * ((it + rot) & (NI - 1))) << 7) + s * 32;
+        xk[mt][it][s] = *reinterpret_cast<const bf16x8*>(((k < p.K0) ? xa : xb) + k);
+      }
+    rstd[mt] = 1.f;
+  }
+  if (do_norm) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float xv = (float)xk[it][s][j]; ssq = fmaf(xv, xv, ssq); }
-    ssq += __shfl_xor(ssq, 16, 64);
-    ssq += __shfl_xor(ssq, 32, 64);
-    if (g == 0) red_ss[wave][r16] = ssq;
+    for (int mt = 0; mt < MT; ++mt) {
+      float ssq = 0.f;
+#pragma unroll
+      for (int it = 0; it < NI; ++it)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const float xv = (float)xk[mt][it][s][j]; ssq = fmaf(xv, xv, ssq); }
+      ssq += __shfl_xor(ssq, 16, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+      if (g == 0) red_ss[wave][mt * 16 + r16] = ssq;
+    }
     __syncthreads();
-    float v = 0.f;
 #pragma unroll
-    for (int w = 0; w < SK_WAVES; ++w) v += red_ss[w][r16];
-    rstd = rsqrtf(v / (float)p.K + p.norm_eps);
+    for (int mt = 0; mt < MT; ++mt) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < SK_WAVES; ++w) v += red_ss[w][mt * 16 + r16];
+      rstd[mt] = rsqrtf(v / (float)p.K + p.norm_eps);
+    }
   }
 
-  f32x4 acc[RT];
+  f32x4 acc[MT][RT];
   for (int ts = 0; ts < n_ts; ++ts) {
 #pragma unroll
-    for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it % S][s][t], xk[it][s], acc[t], 0, 0, 0);
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it % S][s][t], xk[mt][it][s], acc[mt][t], 0, 0, 0);
       // refill this stage with the super-step S ahead (past the last tile-step: clamped rows)
       load_w(a[it % S], ts + (it + S) / NI, (it + S) % NI);
     }
     const int parity = ts & 1;
 #pragma unroll
-    for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(&red[parity][wave][t][lane][0]) = acc[t];
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) *reinterpret_cast<f32x4*>(&red[parity][wave][mt * RT + t][lane][0]) = acc[mt][t];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wave == (ts & (SK_WAVES - 1))) {
-      f32x4 sum[RT];
 #pragma unroll
-      for (int t = 0; t < RT; ++t) {
-        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x4 sum[RT];
 #pragma unroll
-        for (int w = 0; w < SK_WAVES; ++w) sv += *reinterpret_cast<const f32x4*>(&red[parity][w][t][lane][0]);
-        sum[t] = sv * rstd;
-      }
-      const int m = r16;
-      if (m < p.M) {
+        for (int t = 0; t < RT; ++t) {
+          f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int u = 0; u < RTW; ++u) {
-          const int nb = row_lo + ts * RPS + u * 16 + 4 * g;
-          float y[4];
-          if (EPI == EPI_SILU_MUL) {
+          for (int w = 0; w < SK_WAVES; ++w) sv += *reinterpret_cast<const f32x4*>(&red[parity][w][mt * RT + t][lane][0]);
+          sum[t] = sv * rstd[mt];
+        }
+        const int m = mt * 16 + r16;
+        if (m < p.M) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float gt = rbf(sum[2 * u][r]), up = rbf(sum[2 * u + 1][r]);
-              y[r] = rbf(gt / (1.0f + __expf(-gt))) * up;
+          for (int u = 0; u < RTW; ++u) {
+            const int nb = row_lo + ts * RPS + u * 16 + 4 * g;
+            float y[4];
+            if (EPI == EPI_SILU_MUL) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const float gt = rbf(sum[2 * u][r]), up = rbf(sum[2 * u + 1][r]);
+                y[r] = rbf(gt / (1.0f + __expf(-gt))) * up;
+              }
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int n = nb + r;
+                float v = sum[u][r];
+                if (p.bias && n < row_hi) v += bf2f(p.bias[n]);
+                v = rbf(v);
+                if (p.res && n < row_hi) v = v + bf2f(p.res[(int64_t)m * p.ldr + n]);
+                y[r] = v;
+              }
             }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int n = nb + r;
-              float v = sum[u][r];
-              if (p.bias && n < row_hi) v += bf2f(p.bias[n]);
-              v = rbf(v);
-              if (p.res && n < row_hi) v = v + bf2f(p.res[(int64_t)m * p.ldr + n]);
-              y[r] = v;
+            bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
+            if (nb + 3 < row_hi && ((p.ldo | nb) & 3) == 0) {
+              uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+              *reinterpret_cast<uint2*>(o) = v;
+            } else {
+              for (int r = 0; r < 4; ++r) if (nb + r < row_hi) o[r] = f2bf(y[r]);
             }
-          }
-          bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
-          if (nb + 3 < row_hi && ((p.ldo | nb) & 3) == 0) {
-            uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
-            *reinterpret_cast<uint2*>(o) = v;
-          } else {
-            for (int r = 0; r < 4; ++r) if (nb + r < row_hi) o[r] = f2bf(y[r]);
           }
         }
       }
@@ -612,7 +633,7 @@ static int sk_num_cus() {
 #define EAGLE_GEMM_KEEP_RESIDENT 0x100
 static bool sk_stream_nt(const SkinnyArgs& a, int epi) { (void)epi; return a.nt; }
 
-template <int RT, int EPI>
+template <int RT, int EPI, int MT = 1>
 static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
   int grid = sk_num_cus() * g_sk_keepx_bpc;
   int R = (a.N + grid - 1) / grid;
@@ -620,13 +641,15 @@ static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
   R = (R + 3) & ~3;
   grid = (a.N + R - 1) / R;
   const bool nt = sk_stream_nt(a, EPI);
-  if (g_sk_keepx_stages == 4) {
-    if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
-    else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
-  } else {
-    if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 2>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
-    else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 2>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  if constexpr (MT == 1) {
+    if (g_sk_keepx_stages == 4) {
+      if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+      else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+      return eagle_check_launch();
+    }
   }
+  if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 2, MT>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 2, MT>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
   return eagle_check_launch();
 }
 
@@ -703,6 +726,9 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
       // ends sooner (lm_head 32000 x 4096 from cold caches 52.2 -> 49.0 us, in-cycle 53.7 -> 52.4; tools/skinny_sweep.py)
       else if (g_sk_keepx_rt == 2) rc = launch_skinny_keepx<2, EPI_LINEAR>(a, stream);
       else rc = launch_skinny_keepx<1, EPI_LINEAR>(a, stream);
+    } else if (mc > 16 && mc <= 32 && K == 128 * SK_WAVES * 4 && epi == EPI_LINEAR && N >= 8192 && (var == 2 || var == 3)) {
+      // 17-32 rows against a tall matrix (the lm_head of a 32-request batch at one row each): both 16-row x tiles in registers
+      rc = launch_skinny_keepx<1, EPI_LINEAR, 2>(a, stream);
     } else if (mc <= 16 && (K & 127) == 0 && K >= 128 * SK_WAVES && (var == 1 || var == 2 || (var == 3 && K >= 8192)) &&
                !(g_sk_silu_tile && epi == EPI_SILU_MUL)) {
       if (epi == EPI_SILU_MUL) rc = launch_skinny_stream<2, EPI_SILU_MUL>(a, stream);

@@ -381,7 +381,11 @@ class Llama2Model(nn.Module):
             a = layer.self_attn
             cache = caches[li]
             xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
-            qkv = ops.linear_rows(xin, self._packed_weights(li))
+            wqkv = self._packed_weights(li)
+            if M <= 32 and wqkv.shape[1] == 4096 and wqkv.shape[0] >= 8192:
+                qkv = ops.linear_skinny(xin, wqkv)            # <= 32 rows, tall matrix: x in registers (keepx, two row tiles)
+            else:
+                qkv = ops.linear_rows(xin, wqkv)
             attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
             ws = self._attn_workspace(B, H, (past_host + q_len) if past_host is not None else max_kv, dev)
             for r0 in range(0, q_len, 16):

@@ -101,7 +101,11 @@ class EagleDrafter:
     # -------------------------------------------------------------- draft side
     def _head_topk(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int, row0: int, n: int):
         """top-k(lm_head(x[idx])) -> flat rows [row0, row0+n) of every request."""
-        if self.model.rows_min <= rows <= self.rows_head_max and self.D % 128 == 0:
+        if 16 < rows <= 32 and self.D == 4096 and self.lm_head.shape[0] >= 8192:
+            # 17-32 rows (a 32-request batch at one row each): both 16-row tiles of x stay in registers of the weight-stream
+            # kernel, which reads 2 KB of every weight row per block step (in-cycle 151936 x 4096: see DESIGN.md section 10)
+            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
+        elif self.model.rows_min <= rows <= self.rows_head_max and self.D % 128 == 0:
             # decode batches: the row-batch weight stream (gather fused; 32 rows of the 151936-row head 257 vs 328 us on
             # the LDS-tiled kernels, tools/rows2_bench.py); past ~64 rows its x re-reads cost what the tiles' do
             logits = ops.linear_rows(x, self.lm_head, idx0=idx, M=rows)
