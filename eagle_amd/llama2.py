@@ -397,7 +397,10 @@ class Llama2Model(nn.Module):
             n = ops.rmsnorm(x, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
             wgu = self._stacked_mlp(li)
             inter = wgu.shape[0] // 2
-            act = ops.linear_rows(n, wgu[:inter], W2=wgu[inter:])
+            if M <= 32 and wgu.shape[1] == 4096:
+                act = ops.silu_mul(ops.linear_skinny(n, wgu))  # <= 32 rows: gate|up as ONE tall matrix on the keepx stream, then SiLU*up
+            else:
+                act = ops.linear_rows(n, wgu[:inter], W2=wgu[inter:])
             x = ops.linear_rows(act, layer.mlp.down_proj.weight, res=x)
         return x
 
