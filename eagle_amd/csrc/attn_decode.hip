@@ -429,8 +429,12 @@ __global__ __launch_bounds__(256) void attn_rope_append_kernel(AttnDecArgs p) {
 
 // grid (max_splits, H / gq, B); hd = 128.  Reads q from q_roped and every key / value row (this call's included) from the cache.
 __global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[4][2][AW_TK * 256];      // per wave: two V tiles; reused for the merge
-  __shared__ float wm[4][AD_MAXM], wl[4][AD_MAXM];
+  // ONE shared object (a second one makes hipcc wait vmcnt(0) for the pending LDS-DMA before every ds_read):
+  // per wave two V tiles (reused for the merge), then the waves' running maxima and sums
+  __shared__ __attribute__((aligned(16))) char lds_all[4 * 2 * AW_TK * 256 + 2 * 4 * AD_MAXM * 4];
+  char (*lds)[2][AW_TK * 256] = reinterpret_cast<char (*)[2][AW_TK * 256]>(lds_all);
+  float (*wm)[AD_MAXM] = reinterpret_cast<float (*)[AD_MAXM]>(lds_all + 4 * 2 * AW_TK * 256);
+  float (*wl)[AD_MAXM] = wm + 4;
   const int split = blockIdx.x, h0 = blockIdx.y * p.gq, b = blockIdx.z;
   const int M = p.M, hd = 128;
   const int rep = p.H / p.HK, hk = h0 / rep;             // gq divides rep: the group's heads share this KV head
@@ -454,7 +458,12 @@ __global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p)
   {
     const bf16_t* qrow = p.q_roped + ((int64_t)b * AD_MAXM + (m < M ? m : 0)) * p.H * hd + (int64_t)h * hd;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 32 * s + 8 * g);   // rows >= M: masked below
+    for (int s = 0; s < 4; ++s) {                      // rows >= M: masked below.  Hidden from hipcc's wait counting like the
+      const bf16_t* src = qrow + 32 * s + 8 * g;        // K loads: a pending plain load would make it drain the DMA at every QK^T
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[s]) : "v"(src) : "memory");
+    }
+    // no wait here: the first tile's loads go out behind these, and vector-memory operations complete in order, so the
+    // counted wait for that tile (AW_WAIT_TILE, ahead of the first QK^T) covers the q fragments too
   }
   f32x4 o[8];
 #pragma unroll
@@ -477,12 +486,27 @@ __global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p)
     for (int kt = 0; kt < 2; ++kt) {
       const int row = min(k0 + 16 * kt + r16, total - 1);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) kf[kt][s] = *reinterpret_cast<const bf16x8*>(kc + (int64_t)row * hd + 32 * s + 8 * g);
+      for (int s = 0; s < 4; ++s) {
+        // hidden from hipcc's wait counting: beside the LDS-DMA above it would wait vmcnt(0) for a plain load before the first
+        // use (draining the tile just issued: no prefetch at all); AW_WAIT_TILE names these registers at the counted wait
+        const bf16_t* src = kc + (int64_t)row * hd + 32 * s + 8 * g;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kf[kt][s]) : "v"(src) : "memory");
+      }
     }
   };
-  auto compute = [&](const bf16x8 (&kf)[2][4], int buf, int wt) {
-    const int k0 = c_begin + wt * AW_TK;
-    f32x4 sc[2];
+  // counted wait for a tile's loads (issued before the N youngest vector-memory operations); every K register is an in/out
+  // operand, so no MFMA that reads them is scheduled above the wait
+#define AW_WAIT_TILE(N, KF)                                                                                          \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                             \
+               : "+v"(KF[0][0]), "+v"(KF[0][1]), "+v"(KF[0][2]), "+v"(KF[0][3]), "+v"(KF[1][0]), "+v"(KF[1][1]),     \
+                 "+v"(KF[1][2]), "+v"(KF[1][3])                                                                      \
+               :: "memory")
+  // A tile is computed in two parts so that the loads of the tile TWO ahead can be issued in between: part 1 consumes the
+  // tile's K registers (QK^T) and its V buffer (the transposing reads), which are then free for the refill; part 2 (softmax,
+  // P.V) runs with two tiles in flight.
+  f32x4 sc[2];
+  aw_s4 vlo[8], vhi[8];
+  auto part1 = [&](const bf16x8 (&kf)[2][4], int buf) {
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       sc[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -490,19 +514,28 @@ __global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p)
       for (int s = 0; s < 4; ++s) sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][s], qf[s], sc[kt], 0, 0, 0);
     }
     // V^T fragments (the tile has landed: the caller waited); requested ahead of the softmax arithmetic
-    const char* Vt = &lds[wave][buf][0];
-    bf16x8 vfr[8];
+    // The transposing reads are inline asm: hipcc cannot tell a ds_read from the LDS bytes a pending LDS-DMA will write and
+    // waits vmcnt(0) before the first one -- which drains the NEXT tile's loads, i.e. the whole prefetch.  This tile's DMA
+    // has landed (AW_WAIT_TILE in the caller); the reads are waited for by the lgkmcnt statement below, which names them.
+    const uint32_t Vt = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)&lds[wave][buf][0]);
 #pragma unroll
     for (int dt = 0; dt < 8; ++dt) {
       const int r0 = 4 * g + tq;
-      const aw_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) aw_s4*)(Vt + aw_off(r0, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
-      const aw_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (__attribute__((address_space(3))) aw_s4*)(Vt + aw_off(r0 + 16, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
-      union { struct { aw_s4 a, b; } s; bf16x8 v; } u;
-      u.s.a = lo; u.s.b = hi;
-      vfr[dt] = u.v;
+      const uint32_t a0 = Vt + aw_off(r0, 2 * dt + (tp >> 1)) + 8 * (tp & 1);
+      const uint32_t a1 = Vt + aw_off(r0 + 16, 2 * dt + (tp >> 1)) + 8 * (tp & 1);
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[dt]) : "v"(a0) : "memory");
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vhi[dt]) : "v"(a1) : "memory");
     }
+    // the reads are done (named: nothing that uses them moves above) and so are the QK^T reads of the K registers: the
+    // caller may refill both
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(vlo[0]), "+v"(vlo[1]), "+v"(vlo[2]), "+v"(vlo[3]), "+v"(vlo[4]), "+v"(vlo[5]), "+v"(vlo[6]), "+v"(vlo[7]),
+                   "+v"(vhi[0]), "+v"(vhi[1]), "+v"(vhi[2]), "+v"(vhi[3]), "+v"(vhi[4]), "+v"(vhi[5]), "+v"(vhi[6]), "+v"(vhi[7]),
+                   "+v"(sc[0]), "+v"(sc[1])
+                 :: "memory");
+  };
+  auto part2 = [&](int wt) {
+    const int k0 = c_begin + wt * AW_TK;
     float x[8], mx = mrun;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
@@ -534,6 +567,13 @@ __global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p)
       mrun = mx;
     }
     lrun += ps;
+    bf16x8 vfr[8];
+#pragma unroll
+    for (int dt = 0; dt < 8; ++dt) {
+      union { struct { aw_s4 a, b; } s; bf16x8 v; } u;
+      u.s.a = vlo[dt]; u.s.b = vhi[dt];
+      vfr[dt] = u.v;
+    }
     bf16x8 pf;                                                         // k-slot (g, j) <-> key 16*(j>>2) + 4g + (j&3)
     pf[0] = (__bf16)p0[0]; pf[1] = (__bf16)p0[1]; pf[2] = (__bf16)p0[2]; pf[3] = (__bf16)p0[3];
     pf[4] = (__bf16)p1[0]; pf[5] = (__bf16)p1[1]; pf[6] = (__bf16)p1[2]; pf[7] = (__bf16)p1[3];
@@ -542,25 +582,28 @@ __global__ __launch_bounds__(AD_THREADS, 2) void attn_wide_kernel(AttnDecArgs p)
   };
 
   bf16x8 kfa[2][4], kfb[2][4];
-  int wt = wave;
+  int wt = wave;                                                       // this wave's tiles: wt, wt + 4, ...  (all conditions wave-uniform)
   if (wt < n_wt) {
     issue(kfa, 0, wt);
+    if (wt + 4 < n_wt) issue(kfb, 1, wt + 4);
     while (true) {
-      int nxt = wt + 4;
-      bool has = nxt < n_wt;                                           // wave-uniform
-      if (has) { issue(kfb, 1, nxt); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      compute(kfa, 0, wt);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // this tile's LDS reads are done before its buffer is refilled
-      if (!has) break;
-      wt = nxt; nxt = wt + 4; has = nxt < n_wt;
-      if (has) { issue(kfa, 0, nxt); asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      compute(kfb, 1, wt);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!has) break;
-      wt = nxt;
+      // tile wt sits in set A; the only younger operations are those of tile wt + 4 (16, if it exists)
+      if (wt + 4 < n_wt) AW_WAIT_TILE(16, kfa); else AW_WAIT_TILE(0, kfa);
+      part1(kfa, 0);
+      if (wt + 8 < n_wt) issue(kfa, 0, wt + 8);                         // set A is free again: two tiles in flight during part 2
+      part2(wt);
+      wt += 4;
+      if (wt >= n_wt) break;
+      if (wt + 4 < n_wt) AW_WAIT_TILE(16, kfb); else AW_WAIT_TILE(0, kfb);
+      part1(kfb, 1);
+      if (wt + 8 < n_wt) issue(kfb, 1, wt + 8);
+      part2(wt);
+      wt += 4;
+      if (wt >= n_wt) break;
     }
+  } else {
+    // a wave without tiles never reaches a counted wait: its q loads must land before their registers are reused
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]) :: "memory");
   }
   // ---- merge the four waves' (m, l, O~) through LDS; one partial record per workgroup ----
   lrun += __shfl_xor(lrun, 16, 64);
