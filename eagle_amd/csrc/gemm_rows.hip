@@ -311,6 +311,184 @@ __global__ __launch_bounds__(GR_NW * 64) void gemm_rows_reduce_kernel(RowsArgs p
 }
 
 // ---------------------------------------------------------------------------------------------
+// The many-tile, 81..128-row case (the lm_head of a 128-row tree step: 151936 x 4096 weights against 128 rows).
+// Measured (tools/rows_wide_bench.py): with 128-column tiles the x rows every tile re-reads through L2 and the
+// MFMA work sit on top of the weight stream instead of under it.  This form gives a workgroup up to 384 columns: eight
+// consumer waves and NO loader waves (2 waves per SIMD: 256 registers each; 96 accumulators and two weight stages of 48 at
+// three 16-column groups per wave), column tiles of equal width in 16-column groups sized so that the grid is a whole number
+// of rounds of one workgroup per CU (151936 columns: 512 tiles of 18-19 groups, two rounds).  A wave owns 1, 2 or 3
+// consecutive groups and runs the loop compiled for that count: an unused slot would have to load SOMETHING to keep the
+// counted waits uniform, and both choices cost -- one shared dead address queues every wave of the chip on one L2 channel
+// (264 vs 236 us at 128256 columns), re-reading the wave's own lines fetches them again (non-temporal lines do not stay: 314).
+// With the LDS-DMA of x issued by the same waves that stream W, nothing here may be visible to hipcc's wait counting (it
+// answers a plain load or a ds_read beside a pending LDS-DMA with vmcnt(0)): the weight loads and the x fragment reads are
+// inline asm, every wait is counted by hand and followed by empty asm statements that name the registers it releases.
+// Per super-step j a wave issues, in this order, its share of x chunk j+2 (XOPS DMA instructions) and weight stage j+2
+// (4 x RT loads, s-major); vector-memory operations complete in order, so at the top of step j "x chunk j has landed" is
+// vmcnt(2 x 4RT + XOPS) and sub-step s of weight stage j is vmcnt((3 - s) RT + 4RT + XOPS).  (Refilling each sub-step's
+// registers as soon as they are consumed was 2-3 % slower.)
+#define GW_NW 8
+#define GW_RT 3                         // most 16-column groups per wave
+template <int N> struct gw_int { static constexpr int value = N; };
+template <int MT>
+__global__ __launch_bounds__(GW_NW * 64) void gemm_rows_wide_kernel(RowsArgs p) {
+  constexpr int S = 2, XS = S + 1;
+  constexpr int XBYTES = MT * 16 * 256;
+  constexpr int XOPS = MT * 4 / GW_NW;
+  static_assert((MT * 4) % GW_NW == 0, "the waves share a chunk evenly");
+  static_assert(MT % 2 == 0, "x fragments in two halves");
+  constexpr int MH = MT / 2;
+  __shared__ __attribute__((aligned(256))) unsigned char xl[XS * XBYTES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
+  const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (orig >> 3);
+  const int g16 = (p.N + 15) >> 4;
+  const int gb = (int)(((int64_t)tile * g16) / p.tiles);                // this tile's 16-column groups: [gb, gb + ng)
+  const int ng = (int)(((int64_t)(tile + 1) * g16) / p.tiles) - gb;     // GW_NW <= ng <= GW_NW * GW_RT (launcher)
+  const int wg0 = (wave * ng) / GW_NW, wgn = ((wave + 1) * ng) / GW_NW - wg0;   // this wave's groups: 1..GW_RT of them
+  const int nj = p.K >> 7;
+  const int rot = p.rotate ? (tile * p.rotate) % nj : 0;
+  auto kstep = [&](int j) { const int jj = j + rot; return jj >= nj ? jj - nj : jj; };
+  const int r16 = lane & 15, g = lane >> 4;
+
+  // x rows of this wave's DMA instructions (4 rows each; 16-byte chunk XOR (row & 15) on the source side); no second,
+  // concatenated x operand in this form: the launcher keeps those on gemm_rows_stream_kernel
+  const bf16_t* pa[XOPS];
+#pragma unroll
+  for (int i = 0; i < XOPS; ++i) {
+    const int row = 4 * (wave * XOPS + i) + g;
+    const int m = row < p.M ? row : p.M - 1;
+    int64_t ra;
+    if (p.ind0) ra = p.idx0[(int64_t)(m / p.ind_n) * p.idx0_bstride + p.ind0[m % p.ind_n]];
+    else ra = p.idx0 ? p.idx0[m] : m;
+    const int ch = r16 ^ (row & 15);
+    pa[i] = p.x0 + ra * p.ld0 + ch * 8;
+  }
+  auto issue_x = [&](int j) {                              // past the last chunk: the last chunk again, into a buffer nobody reads
+    const int k = kstep(j < nj ? j : nj - 1) << 7;
+    unsigned char* dst = xl + (j % XS) * XBYTES;
+#pragma unroll
+    for (int i = 0; i < XOPS; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa[i] + k),
+                                       (__attribute__((address_space(3))) void*)(dst + (wave * XOPS + i) * 1024), 16, 0, 0);
+  };
+  const uint32_t xl0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)xl) + r16 * 256;
+
+  auto run = [&](auto rt_c) {
+    constexpr int RT = decltype(rt_c)::value;
+    const bf16_t* wp[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+      int n = (gb + wg0 + t) * 16 + r16;
+      n = n < p.N ? n : p.N - 1;                           // the last group of the last tile: clamped rows are never stored
+      wp[t] = p.W + (int64_t)n * p.ldw + 8 * g;
+    }
+    bf16x8 a[S][4][RT];
+    auto issue_w = [&](bf16x8 (&st)[4][RT], int j) {       // past the last super-step: one hot line (two stages per wave)
+      const bool live = j < nj;
+      const int k = live ? kstep(j) << 7 : 0;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)                          // s-major: the order the counted waits rely on
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          const bf16_t* src = live ? wp[t] + k : p.W;
+          if (s == 0) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+          if (s == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:64 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+          if (s == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:128 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+          if (s == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:192 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+        }
+    };
+    f32x4 acc[MT][RT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue_x(0); issue_w(a[0], 0);
+    issue_x(1); issue_w(a[1], 1);
+
+    auto step = [&](bf16x8 (&st)[4][RT], int j) {
+      // x chunk j (every wave's share): behind it in the queue are weight stage j and all of step j-1's issues
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * 4 * RT + XOPS) : "memory");
+      const uint32_t xb = xl0 + (j % XS) * XBYTES;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((3 - s) * RT + 4 * RT + XOPS) : "memory");
+#pragma unroll
+        for (int t = 0; t < RT; ++t) asm volatile("" : "+v"(st[s][t]));      // released by the wait above
+        const uint32_t ad = xb + (((4 * s + g) ^ r16) << 4);
+        bf16x8 xf[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[mt]) : "v"(ad), "n"(mt * 4096) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(MH) : "memory");
+#pragma unroll
+        for (int mt = 0; mt < MH; ++mt) asm volatile("" : "+v"(xf[mt]));
+#pragma unroll
+        for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+          for (int t = 0; t < RT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[s][t], xf[mt], acc[mt][t], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mt = MH; mt < MT; ++mt) asm volatile("" : "+v"(xf[mt]));
+#pragma unroll
+        for (int mt = MH; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < RT; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st[s][t], xf[mt], acc[mt][t], 0, 0, 0);
+      }
+      issue_x(j + S);                                      // into the buffer of chunk j-1: every wave is past barrier j
+      issue_w(st, j + S);
+    };
+    for (int j0 = 0; j0 < nj; j0 += 2) {
+      step(a[0], j0);
+      if (j0 + 1 < nj) step(a[1], j0 + 1);
+    }
+    // the dead refills (and the DMA of a chunk nobody reads) land before the registers and the LDS are given up
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int st = 0; st < S; ++st)
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) asm volatile("" : "+v"(a[st][s][t]));
+
+    // ---- epilogue: acc[mt][t][r] = y[m = mt*16 + r16][n = (gb + wg0 + t)*16 + 4g + r] ----
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = mt * 16 + r16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
+        const int nb = (gb + wg0 + t) * 16 + 4 * g;
+        if (nb >= p.N) continue;
+        float y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nb + r;
+          float v = acc[mt][t][r];
+          if (p.bias && n < p.N) v += bf2f(p.bias[n]);
+          v = rbf(v);
+          if (p.res && n < p.N) v = v + bf2f(p.res[(int64_t)m * p.ldr + n]);
+          y[r] = v;
+        }
+        bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
+        if (nb + 3 < p.N && ((p.ldo | nb) & 3) == 0) {
+          uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+          *reinterpret_cast<uint2*>(o) = v;
+        } else {
+          for (int r = 0; r < 4; ++r) if (nb + r < p.N) o[r] = f2bf(y[r]);
+        }
+      }
+    }
+  };
+  // every variant passes the same nj barriers
+  if (wgn >= 3) run(gw_int<3>{});
+  else if (wgn == 2) run(gw_int<2>{});
+  else run(gw_int<1>{});
+}
+
+// ---------------------------------------------------------------------------------------------
 static int g_rows_target_wg = 0;    // 0: by shape; diagnostics (eagle_debug_set_rows): workgroups the K split aims for
 static int g_rows_min_steps = 4;    // least super-steps per K slice
 static int g_rows_stages = 0;       // 0: default; 2 / 3 / 4 weight register stages (+ 0x10 * (1 + stagger): K-walk stagger override)
@@ -319,10 +497,12 @@ static int g_rows_rotate = 1;
 // writes 16-64 KB, a tile's last arriver would read 128-512 KB alone while the other CUs idle -- o_proj at 32 rows 17.5 us
 // in one launch against 10.2 + 4.0 in two, at 128 rows 38.6 against 22.4 + 5.1.  The in-launch form stays selectable.
 static int g_rows_two_launch = 1;
+static int g_rows_wide = 1;          // gemm_rows_wide_kernel for the many-tile, 81..128-row case (bit 9 of `stages` clears it)
 extern "C" void eagle_debug_set_rows(int target_wg, int min_steps, int stages) {
   g_rows_target_wg = target_wg > 0 ? target_wg : 0;
   g_rows_min_steps = min_steps > 0 ? min_steps : 4;
   g_rows_two_launch = ((stages >> 8) & 1) ? 0 : 1;
+  g_rows_wide = ((stages >> 9) & 1) ? 0 : 1;
   stages &= 0xff;
   g_rows_stages = stages & 15;
   g_rows_rotate = (stages >> 4) ? (stages >> 4) - 1 : 1;
@@ -337,8 +517,8 @@ static int gr_num_cus() {
   }
   return n;
 }
-struct RowsPlan { int mt, tiles, ks, kchunk; };
-static RowsPlan gr_plan(int M, int N, int K, int epi) {
+struct RowsPlan { int mt, tiles, ks, kchunk, wide; };
+static RowsPlan gr_plan(int M, int N, int K, int epi, bool has_x1 = false) {
   RowsPlan pl;
   const int mt = (M + 15) / 16;
   pl.mt = mt <= 2 ? 2 : mt <= 4 ? 4 : mt <= 6 ? 6 : mt <= 8 ? 8 : 12;
@@ -352,6 +532,14 @@ static RowsPlan gr_plan(int M, int N, int K, int epi) {
   if (ks < 1 || pl.tiles * 4 > GR_COUNTER_BYTES) ks = 1;
   pl.kchunk = (nj + ks - 1) / ks;
   pl.ks = (nj + pl.kchunk - 1) / pl.kchunk;              // every slice non-empty
+  pl.wide = 0;
+  const int g16 = (N + 15) / 16, cus = gr_num_cus();
+  if (g_rows_wide && epi == GR_EPI_LINEAR && pl.ks == 1 && (pl.mt == 6 || pl.mt == 8) && g16 >= 8 * cus && !has_x1) {
+    // whole rounds of one workgroup per CU, each tile at most GW_NW * GW_RT groups wide
+    const int rounds = (g16 + cus * GW_NW * GW_RT - 1) / (cus * GW_NW * GW_RT);
+    pl.wide = 1;
+    pl.tiles = rounds * cus;
+  }
   return pl;
 }
 
@@ -385,7 +573,12 @@ static int gr_launch(const RowsArgs& a, hipStream_t st) {
   }
 }
 template <int EPI>
-static int gr_launch_mt(const RowsArgs& a, int mt, hipStream_t st) {
+static int gr_launch_mt(const RowsArgs& a, int mt, hipStream_t st, int wide) {
+  if (wide) {
+    if (mt == 6) hipLaunchKernelGGL((gemm_rows_wide_kernel<6>), dim3(a.tiles), dim3(GW_NW * 64), 0, st, a);
+    else hipLaunchKernelGGL((gemm_rows_wide_kernel<8>), dim3(a.tiles), dim3(GW_NW * 64), 0, st, a);
+    return eagle_check_launch();
+  }
   switch (mt) {
     case 2: return gr_launch<2, EPI>(a, st);
     case 4: return gr_launch<4, EPI>(a, st);
@@ -415,7 +608,7 @@ extern "C" int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t
   if ((ld0 & 7) || (ldw & 7) || ldw < K || !gr_al16(x0) || !gr_al16(W) || (W2 && !gr_al16(W2))) return EAGLE_ERR_SHAPE;
   if (ld0 < K0 && !idx0 && M > 1) return EAGLE_ERR_SHAPE;
   if (ldo < N || (res && ldr < N)) return EAGLE_ERR_SHAPE;
-  const RowsPlan pl = gr_plan(M, N, K, epi);
+  const RowsPlan pl = gr_plan(M, N, K, epi, x1 != nullptr);
   const int64_t need = pl.ks == 1 ? 0 : GR_COUNTER_BYTES + (int64_t)pl.ks * pl.tiles * GR_NW * (pl.mt * 2) * 64 * 16;
   if (need && (!workspace || workspace_bytes < need || !gr_al16(workspace))) return EAGLE_ERR_ARG;
   RowsArgs a;
@@ -426,9 +619,9 @@ extern "C" int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
   a.out = (bf16_t*)out; a.ldo = ldo;
   a.M = M; a.N = N; a.K = K;
-  a.rotate = g_rows_rotate;
+  a.rotate = pl.wide ? 2 * g_rows_rotate : g_rows_rotate;   // wide tiles: every second 256-byte column (measured: 300 vs 337 us)
   a.tiles = pl.tiles; a.ks = pl.ks; a.kchunk = pl.kchunk;
   a.slab = workspace ? (float*)((char*)workspace + GR_COUNTER_BYTES) : nullptr;
   a.counters = (pl.ks > 1 && !g_rows_two_launch) ? (int*)workspace : nullptr;
-  return epi == GR_EPI_SILU_MUL ? gr_launch_mt<GR_EPI_SILU_MUL>(a, pl.mt, stream) : gr_launch_mt<GR_EPI_LINEAR>(a, pl.mt, stream);
+  return epi == GR_EPI_SILU_MUL ? gr_launch_mt<GR_EPI_SILU_MUL>(a, pl.mt, stream, 0) : gr_launch_mt<GR_EPI_LINEAR>(a, pl.mt, stream, pl.wide);
 }

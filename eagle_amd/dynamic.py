@@ -49,7 +49,7 @@ class EagleDynamicDrafter:
         self.dev, self.D = dev, model.config.hidden_size
         self.keep_debug, self.debug = keep_debug, []
         self.wide_head_rows = 32
-        self.rows_head_max = 64
+        self.rows_head_max = 128
         V = lm_head_weight.shape[0]
         self.caches = [model.new_cache(B, self.cap, dev) for _ in model.layers]      # private: forward() never touches them
         model.set_cache_residency(self.lm_head)

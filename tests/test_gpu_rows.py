@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("M,N,K", [(17, 4096, 4096), (32, 4096, 4096), (33, 6144, 4096), (64, 4096, 8192), (84, 4096, 4096),
                                    (96, 4096, 12288), (128, 4096, 4096), (128, 24576, 4096), (128, 151936, 4096), (32, 151936, 4096),
                                    (1, 128, 128), (20, 1000, 256), (128, 200, 384), (50, 72, 1024), (192, 4096, 4096), (150, 12288, 4096), (161, 4096, 8192),
-                                   (192, 600, 256)])
+                                   (192, 600, 256),
+                                   # the many-tile 81..128-row form (gemm_rows_wide_kernel): whole rounds of up to 384-column tiles
+                                   (96, 151936, 4096), (100, 70000, 256), (128, 40000, 128), (81, 33000, 384), (128, 128256, 1024)])
 def test_gemm_rows_linear(M, N, K):
     from eagle_amd import ops
     g = torch.Generator().manual_seed(M * 131 + N + K)
@@ -62,6 +64,28 @@ def test_gemm_rows_gather_concat_and_double_indirection():
     y = ops.linear_rows(emb.to(dev()), W.to(dev()), idx0=fd[:, row0], x1=hid2.to(dev()), M=B * n,
                         ind0=tree_idx.to(dev()), idx0_bstride=7 * 10)
     close(y, ref, what="rows double indirection")
+
+
+def test_gemm_rows_wide_form_gathered_rows_and_switch():
+    """The 8-wave form takes gathered x rows too, and bit 9 of the diagnostic word routes the same call to the 128-column form:
+    both against fp32 torch (the two walk K from different staggered starting points, so they agree to rounding, not bit for bit)."""
+    from eagle_amd import ops
+    from eagle_amd._hip import lib
+    g = torch.Generator().manual_seed(23)
+    M, N, K = 120, 48000, 512
+    table = torch.randn(500, K, generator=g).to(BF).to(dev())
+    ids = torch.randint(0, 500, (M,), generator=g).to(dev())
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(dev())
+    ref = table[ids].float() @ W.float().t()
+    try:
+        y_wide = ops.linear_rows(table, W, idx0=ids, M=M)
+        lib().eagle_debug_set_rows(0, 0, 0x200)
+        y_narrow = ops.linear_rows(table, W, idx0=ids, M=M)
+    finally:
+        lib().eagle_debug_set_rows(0, 0, 0)
+    close(y_wide, ref, what="rows wide gather")
+    close(y_narrow, ref, what="rows narrow gather")
+    assert (y_wide.float() - y_narrow.float()).abs().max().item() <= 2 ** -5
 
 
 def test_gemm_rows_every_split_and_stage_setting():
