@@ -31,6 +31,7 @@ struct SkinnyArgs {
   int M, N, K;
   bool nt;                                               // host-side only: stream W with non-temporal loads
   int rot;                                               // keepx: neighbouring blocks walk their K super-steps from staggered starts
+  int stage;                                             // keepx: collect a block's outputs in LDS and write them when its stream is done
 };
 
 template <int RT, int MT, int EPI>
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
 // and the super-step loop is fully unrolled: stage parity, x fragment and refill target are static.
 // MT = 16-row activation tiles whose fragments stay in registers (1: <= 16 rows, every tree step of one request; 2: <= 32
 // rows, a 32-request batch at one row each -- each weight fragment then feeds two MFMAs instead of one).
+#define SK_OST_COLS 640
 template <int RT, int EPI, int NI, bool NT, int S = 2, int MT = 1>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
   static_assert(NI % S == 0, "S register stages rotate through the NI super-steps of a tile-step");
@@ -441,8 +443,18 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   constexpr int RPS = RTW * 16;
   __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][MT * RT][64][4];
   __shared__ float red_ss[SK_WAVES][MT * 16];
+  // Output staging.  A tile-step yields 16 * RTW columns of every row: 32-byte pieces of rows that lie ld * 2 bytes apart,
+  // one batch every few microseconds, written back by L2 as partial lines in the middle of the weight stream -- measured
+  // at 151936 x 4096: +0.9 us per output ROW (253 us at 32 rows against 234 at 17 with the same instructions; with
+  // non-temporal stores, which go to memory at once, 292).  The block's outputs wait here instead (its columns are
+  // consecutive: up to SK_OST_COLS of them) and leave as whole rows of the block's column range when its stream is done
+  // (32 rows: 253 -> 230 us).  The copy is a serial tail of ~1.5 us, so the launcher asks for it from M x N >= 400000 only
+  // (the batch-1 lm_head of 32000 columns at 1-8 rows is faster without: 52.7 vs 54.2 us).
+  __shared__ __attribute__((aligned(16))) bf16_t ost[MT * 16][SK_OST_COLS + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
+  const bool stage_out = p.stage && rows_per_block <= SK_OST_COLS && ((rows_per_block | (int)(p.ldo & 7)) & 7) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
   const int row_lo = blockIdx.x * rows_per_block;
   const int row_hi = min(p.N, row_lo + rows_per_block);
   if (row_lo >= row_hi) return;
@@ -580,6 +592,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
                 y[r] = v;
               }
             }
+            if (stage_out) {                       // columns past row_hi are staged too and never copied out
+              uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
+              *reinterpret_cast<uint2*>(&ost[m][nb - row_lo]) = v;
+              continue;
+            }
             bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
             if (nb + 3 < row_hi && ((p.ldo | nb) & 3) == 0) {
               uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
@@ -591,6 +608,17 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
         }
       }
     }
+  }
+  if (!stage_out) return;
+  __syncthreads();
+  const int ncols = row_hi - row_lo, cpr = (ncols + 7) >> 3;        // 16-byte chunks per row
+  const int mrows = min(p.M, MT * 16);
+  for (int idx = threadIdx.x; idx < mrows * cpr; idx += SK_WAVES * 64) {
+    const int row = idx / cpr, c8 = (idx - row * cpr) * 8;
+    const bf16_t* src = &ost[row][c8];
+    bf16_t* o = p.out + (int64_t)row * p.ldo + row_lo + c8;
+    if (c8 + 8 <= ncols) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(src);
+    else for (int r = 0; c8 + r < ncols; ++r) o[r] = src[r];
   }
 }
 
@@ -638,7 +666,7 @@ static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
   int grid = sk_num_cus() * g_sk_keepx_bpc;
   int R = (a.N + grid - 1) / grid;
   if (R < 16) R = 16;
-  R = (R + 3) & ~3;
+  R = (R + 7) & ~7;                                    // 16-byte runs when the staged outputs are copied out
   grid = (a.N + R - 1) / R;
   const bool nt = sk_stream_nt(a, EPI);
   if constexpr (MT == 1) {
@@ -717,6 +745,7 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     a.res = res ? (const bf16_t*)res + (int64_t)m0 * ldr : nullptr; a.ldr = ldr;
     a.out = (bf16_t*)out + (int64_t)m0 * ldo; a.ldo = ldo;
     a.M = mc; a.N = N; a.K = K; a.nt = !keep_resident; a.rot = g_sk_rot;
+    a.stage = (int64_t)mc * N >= 400000 ? 1 : 0;
     int rc;
     const int var = skinny_variant();   // 3 = per-shape choice (measured); 0/1/2 force one kernel family
     const bool big = (epi == EPI_SILU_MUL) || N >= 8192;

@@ -117,9 +117,19 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16
     if (lane == 0) lse_part[(int64_t)row * nwc + wc] = make_float2(mx, sm);
   }
   // valid keys are > 0: the smallest value part is 0x007f (-inf); NaN patterns map to 0xffff
-  uint32_t best = 0;
+  // The selection is VALU-bound (19072 waves at 128 rows x 151936 logits), and most of it was the winner's rescan of its 16
+  // keys after every round.  Each lane keeps its best AND its second-best key (keys are distinct: the slot is part of the
+  // key); a lane that wins falls back on its second key at once and rescans only if it wins again before that -- 0.7
+  // times per wave at k = 10 instead of 10 times.  Winners leave in decreasing order, so a lane's consumed keys are
+  // exactly its keys >= the key it has just lost.
+  uint32_t best = 0, second = 0;
 #pragma unroll
-  for (int i = 0; i < TK_PER_LANE; ++i) best = key[i] > best ? key[i] : best;
+  for (int i = 0; i < TK_PER_LANE; ++i) {
+    const uint32_t lo = key[i] < best ? key[i] : best;
+    second = lo > second ? lo : second;
+    best = key[i] > best ? key[i] : best;
+  }
+  bool second_valid = true;
   unsigned long long* out = cand + ((int64_t)row * nwc + wc) * k;
   for (int r = 0; r < k; ++r) {
     const uint32_t bm = wave_umax(best);
@@ -133,11 +143,19 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_bf16_kernel(const bf16
       out[r] = o;
     }
     if (bm != 0 && best == bm) {
-      best = 0;
+      if (second_valid) {
+        best = second;
+        second_valid = false;
+      } else {
+        best = 0; second = 0;
 #pragma unroll
-      for (int i = 0; i < TK_PER_LANE; ++i) {
-        if (key[i] == bm) key[i] = 0;
-        best = key[i] > best ? key[i] : best;
+        for (int i = 0; i < TK_PER_LANE; ++i) {
+          const uint32_t kk = key[i] < bm ? key[i] : 0u;
+          const uint32_t lo = kk < best ? kk : best;
+          second = lo > second ? lo : second;
+          best = kk > best ? kk : best;
+        }
+        second_valid = true;
       }
     }
   }
