@@ -526,8 +526,22 @@ static RowsPlan gr_plan(int M, int N, int K, int epi, bool has_x1 = false) {
   pl.tiles = (N + bn - 1) / bn;
   const int nj = K >> 7;
   const int target = g_rows_target_wg ? g_rows_target_wg : gr_num_cus() * (pl.mt >= 6 ? 1 : 2);
-  int ks = (target + pl.tiles / 2) / pl.tiles;           // nearest count of slices
   const int ks_max = nj / g_rows_min_steps;
+  int ks = 1;
+  if (g_rows_target_wg) {
+    ks = (target + pl.tiles / 2) / pl.tiles;             // diagnostics: nearest count of slices
+  } else {
+    // Whole rounds: `target` workgroups run at a time (one per CU from 96 rows up: 128 KB of x buffers), so 288 of them take
+    // as long as 512 (q|k|v of 128 rows x 12288 columns: 96 tiles x 3 slices, 45.6 us; x 2 slices, one round).  Cost of a
+    // split in super-steps: rounds x (super-steps per slice + ~4 of ramp and drain) + the slices the reduction reads.
+    float best = 0.f;
+    for (int c = 1; c <= (ks_max < 1 ? 1 : ks_max); ++c) {
+      const int kc = (nj + c - 1) / c, real = (nj + kc - 1) / kc;
+      const int rounds = (pl.tiles * real + target - 1) / target;
+      const float cost = (float)rounds * (float)(kc + 4) + 0.25f * (float)real;
+      if (c == 1 || cost < best) { best = cost; ks = real; }
+    }
+  }
   if (ks > ks_max) ks = ks_max;
   if (ks < 1 || pl.tiles * 4 > GR_COUNTER_BYTES) ks = 1;
   pl.kchunk = (nj + ks - 1) / ks;
