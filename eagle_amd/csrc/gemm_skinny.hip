@@ -436,7 +436,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
 // MT = 16-row activation tiles whose fragments stay in registers (1: <= 16 rows, every tree step of one request; 2: <= 32
 // rows, a 32-request batch at one row each -- each weight fragment then feeds two MFMAs instead of one).
 #define SK_OST_COLS 640
-template <int RT, int EPI, int NI, bool NT, int S = 2, int MT = 1>
+template <int RT, int EPI, int NI, bool NT, int S = 2, int MT = 1, bool STAGE = false>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
   static_assert(NI % S == 0, "S register stages rotate through the NI super-steps of a tile-step");
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;
@@ -450,10 +450,10 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   // consecutive: up to SK_OST_COLS of them) and leave as whole rows of the block's column range when its stream is done
   // (32 rows: 253 -> 230 us).  The copy is a serial tail of ~1.5 us, so the launcher asks for it from M x N >= 400000 only
   // (the batch-1 lm_head of 32000 columns at 1-8 rows is faster without: 52.7 vs 54.2 us).
-  __shared__ __attribute__((aligned(16))) bf16_t ost[MT * 16][SK_OST_COLS + 8];
+  __shared__ __attribute__((aligned(16))) bf16_t ost[STAGE ? MT * 16 : 1][STAGE ? SK_OST_COLS + 8 : 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
-  const bool stage_out = p.stage && rows_per_block <= SK_OST_COLS && ((rows_per_block | (int)(p.ldo & 7)) & 7) == 0 &&
+  const bool stage_out = STAGE && rows_per_block <= SK_OST_COLS && ((rows_per_block | (int)(p.ldo & 7)) & 7) == 0 &&
                          ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
   const int row_lo = blockIdx.x * rows_per_block;
   const int row_hi = min(p.N, row_lo + rows_per_block);
@@ -675,6 +675,11 @@ static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
       else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
       return eagle_check_launch();
     }
+  }
+  if (a.stage) {                                       // the instantiation that collects its outputs in LDS (see the kernel)
+    if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 2, MT, true>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+    else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 2, MT, true>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+    return eagle_check_launch();
   }
   if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 2, MT>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
   else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 2, MT>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
