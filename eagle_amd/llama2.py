@@ -312,15 +312,16 @@ class Llama2Model(nn.Module):
         emb_w = self.embed_tokens.weight
         if emb_w.dtype != torch.bfloat16:
             raise TypeError("embed_tokens must be bf16 (cast the model with .to(torch.bfloat16))")
-        if emb_ind is not None and M > 64:
-            # wide batches: resolve flat_topk[tree_indices] into a plain id array first (the fused double
-            # indirection of the weight-stream GEMM covers one 64-row pass)
-            emb_idx = ops.tree_gather_ids(emb_idx, emb_ind, B=B, batch_stride=emb_bstride).reshape(-1)
-            emb_ind, emb_bstride = None, 0
         # decode batches (a batch of requests stepping through the tree together: 17..192 rows): every projection is one
         # weight pass of the row-batch weight stream (W to registers, x through LDS, K split where the matrix is small)
         mid = self.rows_min <= M <= ops.ROWS_MAX and self.config.hidden_size % 128 == 0 and self.config.intermediate_size % 128 == 0 \
             and hid.dim() == 2 and hid.stride(1) == 1
+        if emb_ind is not None and M > 64 and not mid:
+            # wide batches off the row-batch stream: resolve flat_topk[tree_indices] into a plain id array first (the fused
+            # double indirection of the weight-stream GEMM covers one 64-row pass; the row-batch stream's loader takes it at
+            # any row count, so a 128-row tree step needs no such launch)
+            emb_idx = ops.tree_gather_ids(emb_idx, emb_ind, B=B, batch_stride=emb_bstride).reshape(-1)
+            emb_ind, emb_bstride = None, 0
         if mid:
             return self._forward_rows_mid(emb_idx, hid, hid_idx, M, B, q_len, pos, past_dev, max_kv, tmask, pad, caches,
                                           past_host, past_off0, pos_off, pos_stride, emb_ind, emb_bstride, cos, sin)
@@ -398,7 +399,9 @@ class Llama2Model(nn.Module):
             wgu = self._stacked_mlp(li)
             inter = wgu.shape[0] // 2
             if M <= 32 and wgu.shape[1] == 4096:
-                act = ops.silu_mul(ops.linear_skinny(n, wgu))  # <= 32 rows: gate|up as ONE tall matrix on the keepx stream, then SiLU*up
+                # <= 32 rows: gate|up as ONE tall matrix on the keepx stream, then SiLU*up (50 us; the SiLU epilogue on two
+                # row tiles and two weight tiles per step spills: 74)
+                act = ops.silu_mul(ops.linear_skinny(n, wgu))
             else:
                 act = ops.linear_rows(n, wgu[:inter], W2=wgu[inter:])
             x = ops.linear_rows(act, layer.mlp.down_proj.weight, res=x)
