@@ -46,6 +46,7 @@ struct RowsArgs {
   float* slab;             // ks > 1: [ks][tiles][GR_NW][MT*RT][64] f32x4
   int* counters;           // ks > 1 and in-launch reduction: [tiles], zero on entry, zero on exit
   int rotate;              // K-walk stagger between neighbouring column tiles, in super-steps (0: none)
+  int tile_cols;           // gemm_rows_stream_kernel: output columns per column tile: BN, or 3/4 BN with the fourth consumer wave idle
 };
 
 template <int RT, int EPI> struct RowsGeom {
@@ -59,10 +60,10 @@ __device__ __forceinline__ void rows_epilogue(const RowsArgs& p, int tile, int w
   using G = RowsGeom<RT, EPI>;
   const int r16 = lane & 15, g = lane >> 4;
   const int m = mt * 16 + r16;
-  if (m >= p.M) return;
+  if (m >= p.M || w * G::RTW * 16 >= p.tile_cols) return;   // (a narrower tile: its last wave's columns belong to the next tile)
 #pragma unroll
   for (int u = 0; u < G::RTW; ++u) {
-    const int nb = tile * G::BN + (w * G::RTW + u) * 16 + 4 * g;
+    const int nb = tile * p.tile_cols + (w * G::RTW + u) * 16 + 4 * g;
     if (nb >= p.N) continue;
     float y[4];
     if (EPI == GR_EPI_SILU_MUL) {
@@ -155,6 +156,13 @@ __global__ __launch_bounds__((GR_NW + NL) * 64) void gemm_rows_stream_kernel(Row
       if (j + XS - 1 < nj) issue(j + XS - 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (wave * G::RTW * 16 >= p.tile_cols) {
+    // ---------------- a consumer wave past a narrower tile: it only keeps the barrier count ----------------
+    for (int j = 0; j < nj; ++j) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   } else {
   // ---------------- consumer waves: W -> VGPR, MFMA against x fragments from LDS ----------------
   const int r16 = lane & 15, g = lane >> 4;
@@ -162,7 +170,7 @@ __global__ __launch_bounds__((GR_NW + NL) * 64) void gemm_rows_stream_kernel(Row
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     const int u = (EPI == GR_EPI_SILU_MUL) ? (t >> 1) : t;
-    int n = tile * G::BN + (wave * G::RTW + u) * 16 + r16;
+    int n = tile * p.tile_cols + (wave * G::RTW + u) * 16 + r16;
     n = n < p.N ? n : p.N - 1;                           // clamped rows compute values that are never stored
     const bf16_t* base = (EPI == GR_EPI_SILU_MUL && (t & 1)) ? p.W2 : p.W;
     wp[t] = base + (int64_t)n * p.ldw + 8 * g + ((int64_t)j_beg << 7);
@@ -228,7 +236,7 @@ __global__ __launch_bounds__((GR_NW + NL) * 64) void gemm_rows_stream_kernel(Row
   }
   const int64_t slab_wave = (int64_t)GR_NW * (MT * RT) * 64;                     // f32x4 per (slice, tile)
   constexpr int WAVE_SLAB = MT * RT * 1024;               // bytes one consumer wave writes
-  if (!loader) {
+  if (!loader && wave * G::RTW * 16 < p.tile_cols) {
     f32x4* sl = reinterpret_cast<f32x4*>(p.slab) + ((int64_t)slice * p.tiles + tile) * slab_wave + wave * (MT * RT) * 64;
     if (p.counters) {                                    // write-through stores
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)sl, 0, WAVE_SLAB, 0x00020000);
@@ -285,7 +293,7 @@ template <int MT, int RT, int EPI>
 __global__ __launch_bounds__(GR_NW * 64) void gemm_rows_reduce_kernel(RowsArgs p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x, mt = blockIdx.y;
-  if (mt * 16 >= p.M) return;
+  if (mt * 16 >= p.M || wave * RowsGeom<RT, EPI>::RTW * 16 >= p.tile_cols) return;
   f32x4 acc[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -497,12 +505,14 @@ static int g_rows_rotate = 1;
 // writes 16-64 KB, a tile's last arriver would read 128-512 KB alone while the other CUs idle -- o_proj at 32 rows 17.5 us
 // in one launch against 10.2 + 4.0 in two, at 128 rows 38.6 against 22.4 + 5.1.  The in-launch form stays selectable.
 static int g_rows_two_launch = 1;
+static int g_rows_narrow = 1;        // 3/4-width column tiles where they fill whole rounds (bit 10 of `stages` clears it)
 static int g_rows_wide = 1;          // gemm_rows_wide_kernel for the many-tile, 81..128-row case (bit 9 of `stages` clears it)
 extern "C" void eagle_debug_set_rows(int target_wg, int min_steps, int stages) {
   g_rows_target_wg = target_wg > 0 ? target_wg : 0;
   g_rows_min_steps = min_steps > 0 ? min_steps : 4;
   g_rows_two_launch = ((stages >> 8) & 1) ? 0 : 1;
   g_rows_wide = ((stages >> 9) & 1) ? 0 : 1;
+  g_rows_narrow = ((stages >> 10) & 1) ? 0 : 1;
   stages &= 0xff;
   g_rows_stages = stages & 15;
   g_rows_rotate = (stages >> 4) ? (stages >> 4) - 1 : 1;
@@ -517,13 +527,14 @@ static int gr_num_cus() {
   }
   return n;
 }
-struct RowsPlan { int mt, tiles, ks, kchunk, wide; };
+struct RowsPlan { int mt, tiles, ks, kchunk, wide, tile_cols; };
 static RowsPlan gr_plan(int M, int N, int K, int epi, bool has_x1 = false) {
   RowsPlan pl;
   const int mt = (M + 15) / 16;
   pl.mt = mt <= 2 ? 2 : mt <= 4 ? 4 : mt <= 6 ? 6 : mt <= 8 ? 8 : 12;
   const int bn = (epi == GR_EPI_SILU_MUL) ? RowsGeom<2, GR_EPI_SILU_MUL>::BN : RowsGeom<2, GR_EPI_LINEAR>::BN;
   pl.tiles = (N + bn - 1) / bn;
+  pl.tile_cols = bn;
   const int nj = K >> 7;
   const int target = g_rows_target_wg ? g_rows_target_wg : gr_num_cus() * (pl.mt >= 6 ? 1 : 2);
   const int ks_max = nj / g_rows_min_steps;
@@ -533,13 +544,21 @@ static RowsPlan gr_plan(int M, int N, int K, int epi, bool has_x1 = false) {
   } else {
     // Whole rounds: `target` workgroups run at a time (one per CU from 96 rows up: 128 KB of x buffers), so 288 of them take
     // as long as 512 (q|k|v of 128 rows x 12288 columns: 96 tiles x 3 slices, 45.6 us; x 2 slices, one round).  Cost of a
-    // split in super-steps: rounds x (super-steps per slice + ~4 of ramp and drain) + the slices the reduction reads.
+    // split in super-steps: rounds x (super-steps per slice x relative ingest per step + ~4 of ramp and drain) + the slices
+    // the reduction reads.  From 96 rows up, tiles of 3/4 the width (the fourth consumer wave idles) are tried too: a step
+    // takes in (weight columns + x rows) x 256 bytes, and 192 tiles on 256 CUs (SiLU*up at 12288 columns) become 256.
     float best = 0.f;
-    for (int c = 1; c <= (ks_max < 1 ? 1 : ks_max); ++c) {
-      const int kc = (nj + c - 1) / c, real = (nj + kc - 1) / kc;
-      const int rounds = (pl.tiles * real + target - 1) / target;
-      const float cost = (float)rounds * (float)(kc + 4) + 0.25f * (float)real;
-      if (c == 1 || cost < best) { best = cost; ks = real; }
+    const int wcols = (epi == GR_EPI_SILU_MUL) ? 2 : 1;  // weight rows per output column
+    for (int narrow = 0; narrow <= ((pl.mt >= 6 && g_rows_narrow) ? 1 : 0); ++narrow) {
+      const int w = narrow ? bn * 3 / 4 : bn;
+      const int tiles = (N + w - 1) / w;
+      const float rel = (float)(wcols * w + pl.mt * 16) / (float)(wcols * bn + pl.mt * 16);
+      for (int c = 1; c <= (ks_max < 1 ? 1 : ks_max); ++c) {
+        const int kc = (nj + c - 1) / c, real = (nj + kc - 1) / kc;
+        const int rounds = (tiles * real + target - 1) / target;
+        const float cost = (float)rounds * ((float)kc * rel + 4.f) + 0.25f * (float)real;
+        if ((c == 1 && !narrow) || cost < best) { best = cost; ks = real; pl.tiles = tiles; pl.tile_cols = w; }
+      }
     }
   }
   if (ks > ks_max) ks = ks_max;
@@ -634,7 +653,7 @@ extern "C" int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t
   a.out = (bf16_t*)out; a.ldo = ldo;
   a.M = M; a.N = N; a.K = K;
   a.rotate = pl.wide ? 2 * g_rows_rotate : g_rows_rotate;   // wide tiles: every second 256-byte column (measured: 300 vs 337 us)
-  a.tiles = pl.tiles; a.ks = pl.ks; a.kchunk = pl.kchunk;
+  a.tiles = pl.tiles; a.ks = pl.ks; a.kchunk = pl.kchunk; a.tile_cols = pl.tile_cols;
   a.slab = workspace ? (float*)((char*)workspace + GR_COUNTER_BYTES) : nullptr;
   a.counters = (pl.ks > 1 && !g_rows_two_launch) ? (int*)workspace : nullptr;
   return epi == GR_EPI_SILU_MUL ? gr_launch_mt<GR_EPI_SILU_MUL>(a, pl.mt, stream, 0) : gr_launch_mt<GR_EPI_LINEAR>(a, pl.mt, stream, pl.wide);

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
                                    (1, 128, 128), (20, 1000, 256), (128, 200, 384), (50, 72, 1024), (192, 4096, 4096), (150, 12288, 4096), (161, 4096, 8192),
                                    (192, 600, 256),
                                    # the many-tile 81..128-row form (gemm_rows_wide_kernel): whole rounds of up to 384-column tiles
-                                   (96, 151936, 4096), (100, 70000, 256), (128, 40000, 128), (81, 33000, 384), (128, 128256, 1024)])
+                                   (96, 151936, 4096), (100, 70000, 256), (128, 40000, 128), (81, 33000, 384), (128, 128256, 1024),
+                                   # 3/4-width column tiles chosen by the round count (q|k|v at 128 / 192 rows) and odd widths beside them
+                                   (128, 12288, 4096), (192, 12288, 4096), (96, 6000, 1024), (128, 12200, 512)])
 def test_gemm_rows_linear(M, N, K):
     from eagle_amd import ops
     g = torch.Generator().manual_seed(M * 131 + N + K)
