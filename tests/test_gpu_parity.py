@@ -63,6 +63,46 @@ def test_gemm_skinny_linear(M, N, K):
     close(y, ref2, what="bias+res")
 
 
+@pytest.mark.parametrize("M,N", [(16, 32000), (32, 32000), (24, 40008), (24, 40004), (13, 31000), (32, 151936), (5, 151936)])
+def test_gemm_skinny_keepx_staged_outputs(M, N):
+    """From M x N >= 400000 the register-resident weight stream (K = 4096) collects a block's outputs in LDS and writes them
+    when its stream is done: against fp32 torch (bias + residual epilogue too), bit for bit against the same call split into
+    row blocks below the threshold (same kernel arithmetic, plain stores), and into a view whose row stride is no multiple
+    of 8 (the plain-store fallback of the same instantiation)."""
+    from eagle_amd import ops
+    K = 4096
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g).to(BF).to(dev())
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(dev())
+    b = torch.randn(N, generator=g).to(BF).to(dev())
+    r = torch.randn(M, N, generator=g).to(BF).to(dev())
+    ref = x.float() @ W.float().t()
+    y = ops.linear_skinny(x, W)
+    close(y, ref, what="keepx staged plain")
+    close(ops.linear_skinny(x, W, bias=b, res=r), (ref + b.float()).to(BF).float() + r.float(), what="keepx staged bias+res")
+    if M <= 16:
+        step = max(1, 399999 // N)                      # rows per call that stay below the staging threshold
+        if step < M:
+            parts = torch.cat([ops.linear_skinny(x[i:i + step], W) for i in range(0, M, step)])
+            assert torch.equal(parts, y)
+    wide = torch.zeros(M, N + 3, dtype=BF, device=dev())
+    ops.linear_skinny(x, W, out=wide[:, :N])
+    assert torch.equal(wide[:, :N], y) and float(wide[:, N:].abs().max()) == 0.0
+
+
+def test_gemm_skinny_keepx_staged_silu():
+    from eagle_amd import ops
+    M, I, K = 16, 28672, 4096
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=g).to(BF).to(dev())
+    Wg = (torch.randn(I, K, generator=g) / K ** 0.5).to(BF).to(dev())
+    Wu = (torch.randn(I, K, generator=g) / K ** 0.5).to(BF).to(dev())
+    ref = torch.nn.functional.silu((x.float() @ Wg.float().t()).to(BF)) * (x.float() @ Wu.float().t()).to(BF)
+    y = ops.linear_skinny(x, Wg, W2=Wu)
+    close(y, ref, what="keepx staged silu*up")
+    assert torch.equal(torch.cat([ops.linear_skinny(x[:8], Wg, W2=Wu), ops.linear_skinny(x[8:], Wg, W2=Wu)]), y)
+
+
 @pytest.mark.parametrize("M,I,K", [(1, 11008, 4096), (8, 12288, 4096), (4, 128, 64), (24, 256, 128)])
 def test_gemm_skinny_silu_mul(M, I, K):
     from eagle_amd import ops
