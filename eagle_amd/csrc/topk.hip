@@ -393,6 +393,107 @@ __global__ __launch_bounds__(TK_FUSED_WAVES * 64) void topk_fused_bf16_kernel(co
   }
 }
 
+// k = 1 over many long rows (the verifier's argmax at every tree node of a request batch: 832 rows x 151936 logits): one
+// workgroup per row reads the row once and writes the index -- no candidate buffer and no second launch (the two-launch
+// form spends 126k one-kilobyte waves on it: 62 + 4.7 us at 4.1 TB/s).  Same order as everywhere: the monotone 16-bit key,
+// NaN largest, -0 == +0, lowest index among equals (a thread scans ascending indices and takes strict improvements only).
+#define TK_AM_THREADS 256
+typedef unsigned short tk_u16x2 __attribute__((ext_vector_type(2)));
+typedef short tk_i16x2 __attribute__((ext_vector_type(2)));
+// two monotone keys from one word of two bf16 (packed 16-bit ops): exact for everything but NaN and -0, which the caller
+// detects (raw halves > 0xff80, keys > 0xff80, a row maximum of +-0) and sends down the exact path
+__device__ __forceinline__ tk_u16x2 tk_fast_keys(uint32_t w) {
+  union { uint32_t u; tk_u16x2 v; tk_i16x2 s; } c; c.u = w;
+  const tk_i16x2 sign = c.s >> 15;                                    // 0xffff for negative halves
+  union { tk_i16x2 s; tk_u16x2 v; } m; m.s = sign;
+  return c.v ^ (m.v | (tk_u16x2){0x8000, 0x8000});
+}
+__global__ __launch_bounds__(TK_AM_THREADS) void argmax_rows_bf16_kernel(const bf16_t* __restrict__ x, int64_t ld, int V,
+                                                                        int64_t* __restrict__ out_idx, bf16_t* __restrict__ out_val,
+                                                                        const int64_t* __restrict__ block_index, int64_t block_rows,
+                                                                        int out_group, int64_t out_gstride) {
+  __shared__ unsigned long long wbest[TK_AM_THREADS / 64];
+  __shared__ int wflag[TK_AM_THREADS / 64];
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (block_index) x += *block_index * block_rows * ld;
+  const bf16_t* xr = x + (int64_t)row * ld;
+  const bool al = ((ld & 7) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const int nvec = al ? V >> 3 : 0;
+  auto reduce = [&](unsigned long long key, int flag, unsigned long long& won) -> int {   // block-wide: best key, OR of flags
+    key = wave_umax64(key);
+    flag = __any(flag) ? 1 : 0;
+    __syncthreads();                                                  // (second use: the first round's reads are done)
+    if (lane == 0) { wbest[wave] = key; wflag[wave] = flag; }
+    __syncthreads();
+    won = 0; int f = 0;
+#pragma unroll
+    for (int w = 0; w < TK_AM_THREADS / 64; ++w) { won = wbest[w] > won ? wbest[w] : won; f |= wflag[w]; }
+    return f;
+  };
+  // ---- fast pass: packed keys, one compare per 16-byte vector, the winning vector re-read at the end ----
+  uint32_t bk = 0, bv = 0, rawmax = 0;                                // best key, its vector; largest raw half (negative NaN: > 0xff80)
+  auto take = [&](const uint4& a, int v) {
+    const tk_u16x2 k0 = tk_fast_keys(a.x), k1 = tk_fast_keys(a.y), k2 = tk_fast_keys(a.z), k3 = tk_fast_keys(a.w);
+    const tk_u16x2 km = __builtin_elementwise_max(__builtin_elementwise_max(k0, k1), __builtin_elementwise_max(k2, k3));
+    union { uint32_t u; tk_u16x2 v; } r0, r1, r2, r3; r0.u = a.x; r1.u = a.y; r2.u = a.z; r3.u = a.w;
+    const tk_u16x2 rm = __builtin_elementwise_max(__builtin_elementwise_max(r0.v, r1.v), __builtin_elementwise_max(r2.v, r3.v));
+    const uint32_t vm = km.x > km.y ? km.x : km.y;
+    const uint32_t rr = rm.x > rm.y ? rm.x : rm.y;
+    rawmax = rr > rawmax ? rr : rawmax;
+    if (vm > bk) { bk = vm; bv = (uint32_t)v; }
+  };
+  int v = t;
+  for (; v + 3 * TK_AM_THREADS < nvec; v += 4 * TK_AM_THREADS) {      // four 16-byte loads in flight per thread
+    const uint4 a0 = *reinterpret_cast<const uint4*>(xr + (int64_t)v * 8);
+    const uint4 a1 = *reinterpret_cast<const uint4*>(xr + (int64_t)(v + TK_AM_THREADS) * 8);
+    const uint4 a2 = *reinterpret_cast<const uint4*>(xr + (int64_t)(v + 2 * TK_AM_THREADS) * 8);
+    const uint4 a3 = *reinterpret_cast<const uint4*>(xr + (int64_t)(v + 3 * TK_AM_THREADS) * 8);
+    take(a0, v); take(a1, v + TK_AM_THREADS); take(a2, v + 2 * TK_AM_THREADS); take(a3, v + 3 * TK_AM_THREADS);
+  }
+  for (; v < nvec; v += TK_AM_THREADS) take(*reinterpret_cast<const uint4*>(xr + (int64_t)v * 8), v);
+  uint32_t bi = 0;
+  if (bk) {                                                           // first element of the winning vector that holds the key
+    const uint4 a = *reinterpret_cast<const uint4*>(xr + (int64_t)bv * 8);
+    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+    bi = 8;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+      const tk_u16x2 kk = tk_fast_keys(w[i]);
+      if (kk.y == bk) bi = 2 * i + 1;
+      if (kk.x == bk) bi = 2 * i;
+    }
+    bi += bv * 8;
+  }
+  for (int i = nvec * 8 + t; i < V; i += TK_AM_THREADS) {              // the unaligned row / the last V % 8 logits
+    union { uint32_t u; tk_u16x2 v; } c; c.u = xr[i];
+    const uint32_t kk = tk_fast_keys(c.u).x;
+    rawmax = c.u > rawmax ? c.u : rawmax;
+    if (kk > bk) { bk = kk; bi = (uint32_t)i; }
+  }
+  // value first, then the lowest index: the same 64-bit order as the candidate records of the two-launch form
+  unsigned long long key = bk ? (((unsigned long long)bk << 48) | (unsigned long long)(0xffffffffu - bi)) : 0ull;
+  unsigned long long won;
+  int special = reduce(key, (rawmax > 0xff80u || bk > 0xff80u) ? 1 : 0, won);
+  const uint32_t wk = (uint32_t)(won >> 48);
+  special |= (wk == 0x8000u || wk == 0x7fffu) ? 1 : 0;                // a row maximum of +-0: -0 == +0 must tie by index
+  if (special) {
+    // ---- exact pass (rows with NaN, or whose maximum is a zero): the monotone key of mono_bf16 on every element ----
+    bk = 0; bi = 0;
+    for (int i = t; i < V; i += TK_AM_THREADS) {
+      const uint32_t kk = mono_bf16(xr[i]);
+      if (kk > bk) { bk = kk; bi = (uint32_t)i; }
+    }
+    key = bk ? (((unsigned long long)bk << 48) | (unsigned long long)(0xffffffffu - bi)) : 0ull;
+    reduce(key, 0, won);
+  }
+  if (t == 0) {
+    const int64_t idx = won ? (int64_t)(0xffffffffu - (uint32_t)(won & 0xffffffffu)) : -1;
+    const int64_t opos = out_group ? (int64_t)(row / out_group) * out_gstride + (int64_t)(row % out_group) : (int64_t)row;
+    out_idx[opos] = idx;
+    if (out_val) out_val[opos] = idx >= 0 ? xr[idx] : (bf16_t)0;
+  }
+}
+
 static int g_topk_two_stage = 0;     // diagnostics (tests): 1 = always the two-launch form, 2 = the one-launch form wherever legal
 extern "C" void eagle_debug_set_topk(int two_stage) { g_topk_two_stage = two_stage; }
 
@@ -414,7 +515,11 @@ static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int 
   dim3 g1((nwc + 3) / 4, rows);
   // one launch where it is the faster form (measured in the batch-1 draft cycle, V = 32000: k = 1 7.6 us against 4.5 + 4.5;
   // k = 10 14.3 us against 5.8 + 6.3 -- ten serial selection rounds on ONE workgroup cost more than the launch they save)
-  if (dtype == 0 && !lse_out && nwc <= TK_FUSED_MAXWC && (k <= 2 || g_topk_two_stage == 2) && g_topk_two_stage != 1) {
+  if (dtype == 0 && !lse_out && k == 1 && nwc > TK_FUSED_MAXWC && rows >= 256 && g_topk_two_stage != 1) {
+    // many long rows: a workgroup per row fills the chip by itself (below ~256 rows the two-launch form spreads a row wider)
+    hipLaunchKernelGGL(argmax_rows_bf16_kernel, dim3(rows), dim3(TK_AM_THREADS), 0, stream, (const bf16_t*)logits, ld, V, out_idx,
+                       (bf16_t*)out_val, block_index, block_rows, out_group, out_gstride);
+  } else if (dtype == 0 && !lse_out && nwc <= TK_FUSED_MAXWC && (k <= 2 || g_topk_two_stage == 2) && g_topk_two_stage != 1) {
 #define TK_FUSED_LAUNCH(CPW) hipLaunchKernelGGL(topk_fused_bf16_kernel<CPW>, dim3(rows), dim3(TK_FUSED_WAVES * 64), 0, stream, \
     (const bf16_t*)logits, ld, V, k, nwc, out_idx, (bf16_t*)out_val, block_index, block_rows, out_group, out_gstride)
     if (nwc <= TK_FUSED_WAVES) TK_FUSED_LAUNCH(1);

@@ -222,6 +222,34 @@ def test_topk_with_row_lse_from_the_same_pass(rows, V):
     assert torch.allclose(lse, ops.row_lse(xd), rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("rows,V,ld", [(300, 70000, 70000), (832, 151936, 151936), (256, 65537 + 6, 65537 + 9), (260, 66001, 66008)])
+def test_argmax_many_long_rows_one_launch(rows, V, ld):
+    """k = 1 over >= 256 rows of more than 65536 logits (the verifier's argmax of a request batch) runs one workgroup per row:
+    the ids of the stable-sort oracle and of the two-launch form, with ties, NaN, -0 / +0 and rows that are not 16-byte
+    aligned (odd leading dimension: the scalar path)."""
+    from eagle_amd import ops
+    from eagle_amd._hip import lib
+    g = torch.Generator().manual_seed(rows + V)
+    buf = (torch.randn(rows, ld, generator=g) * 4).to(BF)
+    x = buf[:, :V]
+    x[0] = 1.0; x[0, [V - 1, 9, 65536]] = 7.0                       # ties: lowest index
+    x[1] = -3.0; x[1, [40000, 12]] = torch.tensor([-0.0, 0.0], dtype=BF)   # -0 == +0: index 12
+    x[2, 69000 % V] = float("nan"); x[2, 5] = float("inf")           # NaN above +inf
+    x[3] = float("-inf"); x[3, V - 3] = -5.0
+    want = ot.first_argmax(x.contiguous())
+    xd = buf.to(dev())[:, :V]
+    try:
+        got = ops.first_argmax(xd)
+        lib().eagle_debug_set_topk(1)
+        two = ops.first_argmax(xd)
+    finally:
+        lib().eagle_debug_set_topk(0)
+    assert torch.equal(got.cpu(), want) and torch.equal(two.cpu(), want)
+    assert got[0].item() == 9 and got[1].item() == 12 and got[2].item() == 69000 % V and got[3].item() == V - 3
+    v, i = ops.topk(xd, 1)
+    assert torch.equal(i[:, 0].cpu(), want) and torch.equal(v[:, 0].cpu()[3:], x[torch.arange(rows), want][3:])
+
+
 def test_topk_vocabulary_smaller_than_k():
     """V < k: the V entries in order, then index -1 / value 0 (the documented contract), bf16 and fp32."""
     from eagle_amd import ops
