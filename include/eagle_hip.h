@@ -386,7 +386,8 @@ void eagle_debug_set_topk(int two_stage);
 /* eagle_gemm_rows_bf16: target_wg > 0 = workgroups the K split aims for (0 = by shape), min_steps = least 128-wide K
  * super-steps per slice (default 4); stages: bits 0-3 = 2 / 3 / 4 weight register stages (0 = default 3), bits 4-7 =
  * 1 + K-walk stagger of neighbouring column tiles (0 = default stagger 1), bit 8 = sum the partial sums inside the launch (last workgroup of a tile to arrive) instead of in a second launch,
- * bit 9 = keep the many-tile 81..128-row case (a 128-row lm_head) on 128-column tiles instead of the up-to-384-column form. */
+ * bit 9 = keep the many-tile 81..128-row case (a 128-row lm_head) on 128-column tiles instead of the up-to-384-column form,
+ * bit 10 = full-width column tiles only (no 3/4-width tiles chosen by the round count). */
 void eagle_debug_set_rows(int target_wg, int min_steps, int stages);
 
 #ifdef __cplusplus

@@ -90,6 +90,30 @@ def test_gemm_rows_wide_form_gathered_rows_and_switch():
     assert (y_wide.float() - y_narrow.float()).abs().max().item() <= 2 ** -5
 
 
+def test_gemm_rows_narrow_tiles_on_and_off():
+    """3/4-width column tiles (picked where they fill whole rounds of resident workgroups) and full-width tiles: the same product,
+    linear with bias + residual and SiLU*up, at 128 and 192 rows."""
+    from eagle_amd import ops
+    from eagle_amd._hip import lib
+    g = torch.Generator().manual_seed(31)
+    for M in (128, 192):
+        N, K = 12288, 1024
+        x = torch.randn(M, K, generator=g).to(BF).to(dev())
+        W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(dev())
+        b = torch.randn(N, generator=g).to(BF).to(dev())
+        r = torch.randn(M, N, generator=g).to(BF).to(dev())
+        ref = ((x.float() @ W.float().t()) + b.float()).to(BF).float() + r.float()
+        Wgu = (torch.randn(2 * 6144, K, generator=g) / K ** 0.5).to(BF).to(dev())
+        refs = torch.nn.functional.silu((x.float() @ Wgu[:6144].float().t()).to(BF)) * (x.float() @ Wgu[6144:].float().t()).to(BF)
+        try:
+            for knob in (0, 0x400):
+                lib().eagle_debug_set_rows(0, 0, knob)
+                close(ops.linear_rows(x, W, bias=b, res=r), ref, what="rows narrow/full tiles")
+                close(ops.linear_rows(x, Wgu[:6144], W2=Wgu[6144:]), refs, what="rows narrow/full tiles silu")
+        finally:
+            lib().eagle_debug_set_rows(0, 0, 0)
+
+
 def test_gemm_rows_every_split_and_stage_setting():
     """The diagnostic knobs select the K split and the register stages: every combination gives the same product."""
     from eagle_amd import ops
