@@ -327,7 +327,7 @@ __global__ __launch_bounds__(GR_NW * 64) void gemm_rows_reduce_kernel(RowsArgs p
 // of rounds of one workgroup per CU (151936 columns: 512 tiles of 18-19 groups, two rounds).  A wave owns 1, 2 or 3
 // consecutive groups and runs the loop compiled for that count: an unused slot would have to load SOMETHING to keep the
 // counted waits uniform, and both choices cost -- one shared dead address queues every wave of the chip on one L2 channel
-// (264 vs 236 us at 128256 columns), re-reading the wave's own lines fetches them again (non-temporal lines do not stay: 314).
+// (264 vs 249 us at 128256 columns), re-reading the wave's own lines fetches them again (non-temporal lines do not stay: 314).
 // With the LDS-DMA of x issued by the same waves that stream W, nothing here may be visible to hipcc's wait counting (it
 // answers a plain load or a ds_read beside a pending LDS-DMA with vmcnt(0)): the weight loads and the x fragment reads are
 // inline asm, every wait is counted by hand and followed by empty asm statements that name the registers it releases.
