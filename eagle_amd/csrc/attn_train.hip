@@ -63,6 +63,12 @@ __device__ __forceinline__ void a2_work(int npairs, int H, int& pair, int& h, in
 #define A2_QB 128
 #define A2_KB 64
 typedef __attribute__((ext_vector_type(4))) short a2_s4;
+// buffer resource over the rows [0, nrows) of a row-major bf16 operand (row stride ld elements): the DMA instructions address
+// it with a 32-bit byte offset per lane
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t a2_rsrc(const bf16_t* base, int64_t ld, int nrows) {
+  const uint64_t bytes = (uint64_t)nrows * (uint64_t)ld * 2ull;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes > 0xffffffffull ? 0xffffffffu : (uint32_t)bytes), 0x00020000);
+}
 __device__ __forceinline__ int a2_off(int row, int ch) {   // byte offset of 16-byte chunk ch of a tile row
   return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
@@ -102,6 +108,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd2_kernel(AttnTrainAr
   // fills 1 KB = 4 rows x 256 B lane-linearly, so the chunk swizzle of a2_off() is applied to the
   // per-lane SOURCE address (lane l: row l>>4, slot l&15 holds chunk slot ^ f(row)).  Never
   // predicated: keys past L re-read the last key row and are masked out of the scores.
+  // (buffer-addressed DMA: beside a pending global_load_lds hipcc waits vmcnt(0) before the first ds_read that follows,
+  // i.e. for the tile just requested -- the prefetch then overlaps nothing; it does not do that for buffer_load ... lds)
+  const __amdgpu_buffer_rsrc_t krs = a2_rsrc(kbase, p.ld, L), vrs = a2_rsrc(vbase, p.ld, L);
   auto stage = [&](int k0, int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -109,14 +118,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd2_kernel(AttnTrainAr
       const int trow = c >> 4, slot = c & 15;
       const int ch = slot ^ (((trow & 3) << 2) | ((trow >> 2) & 3));
       const int row = min(k0 + trow, L - 1);
-      const bf16_t* gk = kbase + (int64_t)row * p.ld + ch * 8;
-      const bf16_t* gv = vbase + (int64_t)row * p.ld + ch * 8;
+      const uint32_t off = (uint32_t)(((int64_t)row * p.ld + ch * 8) * 2);
       char* dk = &lds[buf][0][(i * AT_THREADS + wave * 64) * 16];   // wave-uniform base; HW adds lane*16
       char* dv = &lds[buf][1][(i * AT_THREADS + wave * 64) * 16];
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gk,
-                                       (__attribute__((address_space(3))) void*)dk, 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv,
-                                       (__attribute__((address_space(3))) void*)dv, 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)dk, 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)dv, 16, off, 0, 0, 0);
     }
   };
   stage(0, 0);
@@ -268,16 +274,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // workgroup takes block i and block n-1-i of the causal triangle.
 __device__ __forceinline__ void a2_stage_tile(const bf16_t* gbase, int64_t ld, int row0, int nrows, char* dst, int tid) {
   const int wave = tid >> 6;
+  const __amdgpu_buffer_rsrc_t rs = a2_rsrc(gbase, ld, nrows);       // buffer-addressed: see attn_train_fwd2_kernel
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = i * AT_THREADS + tid;
     const int trow = c >> 4, slot = c & 15;
     const int ch = slot ^ (((trow & 3) << 2) | ((trow >> 2) & 3));
     const int row = min(row0 + trow, nrows - 1);
-    const bf16_t* g = gbase + (int64_t)row * ld + ch * 8;
     char* d = dst + (i * AT_THREADS + wave * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)d, 16,
+                                             (uint32_t)(((int64_t)row * ld + ch * 8) * 2), 0, 0, 0);
   }
 }
 __device__ __forceinline__ bf16x8 a2_row_frag(const char* tile, int row, int ch) {
@@ -432,10 +438,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_dkv2_kernel(AttnTrainAr
     a2_stage_tile(base, p.ld, q0, L, bb, tid);
     a2_stage_tile(dobase, p.lddo, q0, L, bb + A2_TILE_BYTES, tid);
     if (wave < 2) {   // wave-uniform: one 4-byte piece per lane, lane-linear destination
-      const float* src = (wave == 0 ? lse_g : dl_g) + min(q0 + lane, L - 1);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(wave == 0 ? lse_g : dl_g), 0, L * 4, 0x00020000);
       char* d = bb + 2 * A2_TILE_BYTES + wave * (A2_KB * 4);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)d, 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)d, 4, (uint32_t)(min(q0 + lane, L - 1) * 4), 0, 0, 0);
     }
   };
   for (int pass = 0; pass < 2; ++pass) {
