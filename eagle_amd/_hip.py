@@ -51,6 +51,9 @@ SIGNATURES = {
     "eagle_topk_vocab": (I, [P, L, I, I, I, I, P, P, P, P, L, P]),
     "eagle_topk_vocab_grouped": (I, [P, L, I, I, I, I, P, P, P, I, L, P]),
     "eagle_topk_vocab_noalloc": (I, [P, L, I, I, I, I, P, P, P, L, P]),
+    "eagle_topk_merge_candidates": (I, [P, I, I, I, P, P, I, L, P]),
+    "eagle_lm_head_topk_rows_workspace_bytes": (L, [I, I, I, I]),
+    "eagle_lm_head_topk_rows_bf16": (I, [P, P, L, P, I, L, P, L, P, I, I, I, I, P, P, I, L, P, L, P]),
     "eagle_topk_lse_vocab": (I, [P, L, I, I, I, P, P, P, P, P]),
     "eagle_tree_layout": (I, [P, I, I, I, I, P]),
     "eagle_tree_build": (I, [P, I, I, I, I, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -46,6 +46,7 @@ struct RowsArgs {
   float* slab;             // ks > 1: [ks][tiles][GR_NW][MT*RT][64] f32x4
   int* counters;           // ks > 1 and in-launch reduction: [tiles], zero on entry, zero on exit
   int rotate;              // K-walk stagger between neighbouring column tiles, in super-steps (0: none)
+  unsigned long long* cand; int topk;   // gemm_rows_wide_kernel<MT, true>: [M][tiles][topk] candidate records instead of `out`
   int tile_cols;           // gemm_rows_stream_kernel: output columns per column tile: BN, or 3/4 BN with the fourth consumer wave idle
 };
 
@@ -338,15 +339,27 @@ __global__ __launch_bounds__(GR_NW * 64) void gemm_rows_reduce_kernel(RowsArgs p
 #define GW_NW 8
 #define GW_RT 3                         // most 16-column groups per wave
 template <int N> struct gw_int { static constexpr int value = N; };
-template <int MT>
+#define GW_KSTRIDE 800                  // bytes per row of the 16-bit key image (TOPK): 4 rows read side by side hit 4 x 8 banks
+__device__ __forceinline__ uint32_t gw_mono_bf16(bf16_t b) {          // topk.hip's monotone key (NaN largest, -0 == +0)
+  if ((b & 0x7fff) > 0x7f80) return 0xffffu;
+  if (b == 0x8000) b = 0;
+  return (b & 0x8000) ? (uint32_t)(uint16_t)~b : (uint32_t)(b | 0x8000);
+}
+// TOPK: no logits leave the kernel.  A tile's outputs are rounded to bf16, turned into 16-bit monotone keys and laid out in
+// LDS (the x buffers are free by then); every 16-lane group then selects the p.topk best of one row of the tile (lane l holds
+// columns l, l+16, ...: keys = value << 16 | 0xffff - column, the lowest column wins a tie) and writes them as candidate
+// records [row][tile][topk] in topk.hip's format -- eagle_topk_merge_candidates finishes the job.  Against logits + the
+// two-launch top-k this saves the 39 MB store burst of a 128 x 151936 tile row and the 39 MB pass of stage 1.
+template <int MT, bool TOPK = false>
 __global__ __launch_bounds__(GW_NW * 64) void gemm_rows_wide_kernel(RowsArgs p) {
   constexpr int S = 2, XS = S + 1;
   constexpr int XBYTES = MT * 16 * 256;
+  constexpr int LDS_BYTES = (TOPK && MT * 16 * GW_KSTRIDE > XS * XBYTES) ? MT * 16 * GW_KSTRIDE : XS * XBYTES;
   constexpr int XOPS = MT * 4 / GW_NW;
   static_assert((MT * 4) % GW_NW == 0, "the waves share a chunk evenly");
   static_assert(MT % 2 == 0, "x fragments in two halves");
   constexpr int MH = MT / 2;
-  __shared__ __attribute__((aligned(256))) unsigned char xl[XS * XBYTES];
+  __shared__ __attribute__((aligned(256))) unsigned char xl[LDS_BYTES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nwg = gridDim.x, orig = blockIdx.x;
   const int xq = nwg >> 3, xr = nwg & 7, xcd = orig & 7;
@@ -461,6 +474,31 @@ __global__ __launch_bounds__(GW_NW * 64) void gemm_rows_wide_kernel(RowsArgs p) 
 #pragma unroll
         for (int t = 0; t < RT; ++t) asm volatile("" : "+v"(a[st][s][t]));
 
+    if (TOPK) {
+      // ---- key image: keys[m][c] (16 bit) at xl + m * GW_KSTRIDE + 2c, c = column inside the tile ----
+      __syncthreads();                                     // every wave is done with the x buffers
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+          const int cb = (wg0 + t) * 16 + 4 * g;
+          uint32_t k16[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int n = gb * 16 + cb + r;
+            float v = acc[mt][t][r];
+            if (p.bias && n < p.N) v += bf2f(p.bias[n]);
+            k16[r] = n < p.N ? gw_mono_bf16(f2bf(v)) : 0u;
+          }
+          *reinterpret_cast<uint2*>(xl + (mt * 16 + r16) * GW_KSTRIDE + 2 * cb) = make_uint2(k16[0] | (k16[1] << 16), k16[2] | (k16[3] << 16));
+        }
+      if (wave == 0 && ng < GW_NW * GW_RT) {               // the 16 slots after the tile's last group: key 0 (an odd group count)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+          *reinterpret_cast<uint2*>(xl + (mt * 16 + r16) * GW_KSTRIDE + 2 * (ng * 16 + 4 * g)) = make_uint2(0u, 0u);
+      }
+      return;
+    }
     // ---- epilogue: acc[mt][t][r] = y[m = mt*16 + r16][n = (gb + wg0 + t)*16 + 4g + r] ----
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -494,6 +532,71 @@ __global__ __launch_bounds__(GW_NW * 64) void gemm_rows_wide_kernel(RowsArgs p) 
   if (wgn >= 3) run(gw_int<3>{});
   else if (wgn == 2) run(gw_int<2>{});
   else run(gw_int<1>{});
+  if (!TOPK) return;
+  // ---- selection: wave w takes rows 16w .. 16w+15, four at a time (one per 16-lane group) ----
+  __syncthreads();
+  if (wave >= MT) return;                                  // 96-row form: waves 6 and 7 have no rows
+  const int grp = lane >> 4, l16 = lane & 15;
+  // b1 >= b2 >= b3 >= b4 stay the four largest keys seen: one max and three medians per key
+  auto insert4 = [](uint32_t key, uint32_t& b1, uint32_t& b2, uint32_t& b3, uint32_t& b4) {
+    uint32_t n2, n3, n4;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n4) : "v"(b3), "v"(b4), "v"(key));
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n3) : "v"(b2), "v"(b3), "v"(key));
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n2) : "v"(b1), "v"(b2), "v"(key));
+    b1 = key > b1 ? key : b1; b2 = n2; b3 = n3; b4 = n4;
+  };
+  auto group_umax = [](uint32_t v) {                        // the maximum of a 16-lane group, in every lane of the group
+    uint32_t t;
+    t = __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, false); v = v > t ? v : t;   // quad_perm [1,0,3,2]
+    t = __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, false); v = v > t ? v : t;   // quad_perm [2,3,0,1]
+    t = __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xf, 0xf, false); v = v > t ? v : t;  // row_half_mirror
+    t = __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xf, 0xf, false); v = v > t ? v : t;  // row_mirror
+    return v;
+  };
+  for (int pass = 0; pass < 4; ++pass) {
+    const int R = 16 * wave + 4 * pass + grp;
+    const unsigned char* krow = xl + R * GW_KSTRIDE;
+    // Lane l of the group holds columns 32 jj + 2l and + 1 (one 4-byte read per pair, all reads issued before the first is
+    // used); its best FOUR keys below `limit` are kept (keys are distinct: the column is part of the key), so a lane only
+    // looks at its columns again after winning four rounds.  Columns past N and the 16 columns after the tile's last group
+    // hold key 0 (staged so): their 32-bit keys lie below every real one and a tile has >= 128 real columns.
+    auto scan = [&](auto limited, uint32_t limit, uint32_t& b1, uint32_t& b2, uint32_t& b3, uint32_t& b4) {
+      uint32_t w[GW_NW * GW_RT / 2];
+#pragma unroll
+      for (int jj = 0; jj < GW_NW * GW_RT / 2; ++jj)
+        w[jj] = *reinterpret_cast<const uint32_t*>(krow + 2 * (32 * jj + 2 * l16));   // unguarded: the row holds 400 slots
+      b1 = b2 = b3 = b4 = 0;
+#pragma unroll
+      for (int jj = 0; jj < GW_NW * GW_RT / 2; ++jj) {
+        if (32 * jj < 16 * ng) {                           // uniform
+          const uint32_t c = 32 * jj + 2 * l16;
+          uint32_t key0 = (w[jj] << 16) | (0xffffu - c);
+          uint32_t key1 = (w[jj] & 0xffff0000u) | (0xfffeu - c);
+          if (decltype(limited)::value) {
+            key0 = key0 < limit ? key0 : 0u;
+            key1 = key1 < limit ? key1 : 0u;
+          }
+          insert4(key0, b1, b2, b3, b4);
+          insert4(key1, b1, b2, b3, b4);
+        }
+      }
+    };
+    uint32_t b1, b2, b3, b4;
+    scan(gw_int<0>{}, 0u, b1, b2, b3, b4);
+    int wins = 0;
+    unsigned long long* out = p.cand + ((int64_t)R * p.tiles + tile) * p.topk;
+    for (int r = 0; r < p.topk; ++r) {
+      const uint32_t gm = group_umax(b1);
+      if (l16 == 0 && R < p.M) {
+        const uint32_t gidx = (uint32_t)(gb * 16) + (0xffffu - (gm & 0xffffu));
+        out[r] = (gm >> 16) ? (((unsigned long long)(gm & 0xffff0000u) << 32) | (unsigned long long)(0xffffffffu - gidx)) : 0ull;
+      }
+      if (gm != 0 && b1 == gm) {
+        b1 = b2; b2 = b3; b3 = b4; b4 = 0;
+        if (++wins == 4) { scan(gw_int<1>{}, gm, b1, b2, b3, b4); wins = 0; }   // its four known keys are spent: the rest of its columns
+      }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -654,7 +757,57 @@ extern "C" int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t
   a.M = M; a.N = N; a.K = K;
   a.rotate = pl.wide ? 2 * g_rows_rotate : g_rows_rotate;   // wide tiles: every second 256-byte column (measured: 300 vs 337 us)
   a.tiles = pl.tiles; a.ks = pl.ks; a.kchunk = pl.kchunk; a.tile_cols = pl.tile_cols;
+  a.cand = nullptr; a.topk = 0;
   a.slab = workspace ? (float*)((char*)workspace + GR_COUNTER_BYTES) : nullptr;
   a.counters = (pl.ks > 1 && !g_rows_two_launch) ? (int*)workspace : nullptr;
   return epi == GR_EPI_SILU_MUL ? gr_launch_mt<GR_EPI_SILU_MUL>(a, pl.mt, stream, 0) : gr_launch_mt<GR_EPI_LINEAR>(a, pl.mt, stream, pl.wide);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// lm_head + top-k of a 81..128-row tree step without the logits: gemm_rows_wide_kernel<MT, true> leaves k candidate records per
+// (row, column tile) in the workspace, eagle_topk_merge_candidates (topk.hip) picks every row's k best.  Same ids as
+// eagle_gemm_rows_bf16 + eagle_topk_vocab(_grouped) on the bf16 logits (same rounding, same order: value, then lowest index);
+// the values come back from the 16-bit keys (-0 as +0).  Shapes outside the wide form's range return EAGLE_ERR_SHAPE (the
+// caller then takes the two-step path); eagle_lm_head_topk_rows_workspace_bytes returns 0 for them.
+extern "C" int eagle_topk_merge_candidates(const void* cand, int ncand, int rows, int k, int64_t* out_idx, void* out_val,
+                                           int group, int64_t group_stride, hipStream_t stream);
+static bool gr_topk_plan(int M, int N, int K, int k, RowsPlan& pl) {
+  if (M < 81 || M > 128 || N < 1 || K < 128 || (K & 127) || k < 1 || k > 16) return false;
+  pl = gr_plan(M, N, K, GR_EPI_LINEAR, false);
+  return pl.wide && (int64_t)pl.tiles * k <= 256 * 24;
+}
+extern "C" int64_t eagle_lm_head_topk_rows_workspace_bytes(int M, int N, int K, int k) {
+  RowsPlan pl;
+  if (!gr_topk_plan(M, N, K, k, pl)) return 0;
+  return (int64_t)pl.mt * 16 * pl.tiles * k * 8;
+}
+extern "C" int eagle_lm_head_topk_rows_bf16(const void* x0, const int64_t* idx0, int64_t ld0, const int64_t* ind0, int ind_n,
+                                            int64_t idx0_bstride, const void* W, int64_t ldw, const void* bias,
+                                            int M, int N, int K, int k, int64_t* out_idx, void* out_val, int group,
+                                            int64_t group_stride, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+  if (!x0 || !W || !out_idx || !workspace) return EAGLE_ERR_ARG;
+  if (ind0 && (!idx0 || ind_n < 1)) return EAGLE_ERR_ARG;
+  RowsPlan pl;
+  if (!gr_topk_plan(M, N, K, k, pl)) return EAGLE_ERR_SHAPE;
+  if ((ld0 & 7) || (ldw & 7) || ldw < K || !gr_al16(x0) || !gr_al16(W) || (reinterpret_cast<uintptr_t>(workspace) & 7)) return EAGLE_ERR_SHAPE;
+  if (ld0 < K && !idx0 && M > 1) return EAGLE_ERR_SHAPE;
+  if (workspace_bytes < (int64_t)pl.mt * 16 * pl.tiles * k * 8) return EAGLE_ERR_ARG;
+  RowsArgs a;
+  a.x0 = (const bf16_t*)x0; a.idx0 = idx0; a.ld0 = ld0; a.K0 = K;
+  a.ind0 = ind0; a.ind_n = ind_n; a.idx0_bstride = idx0_bstride;
+  a.x1 = nullptr; a.idx1 = nullptr; a.ld1 = 0;
+  a.W = (const bf16_t*)W; a.W2 = nullptr; a.ldw = ldw;
+  a.bias = (const bf16_t*)bias; a.res = nullptr; a.ldr = 0;
+  a.out = nullptr; a.ldo = 0;
+  a.M = M; a.N = N; a.K = K;
+  a.rotate = 2 * g_rows_rotate;
+  a.tiles = pl.tiles; a.ks = 1; a.kchunk = K >> 7; a.tile_cols = 0;
+  a.slab = nullptr; a.counters = nullptr;
+  a.cand = (unsigned long long*)workspace; a.topk = k;
+  if (pl.mt == 6) hipLaunchKernelGGL((gemm_rows_wide_kernel<6, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_rows_wide_kernel<8, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, stream, a);
+  int rc = eagle_check_launch();
+  if (rc) return rc;
+  return eagle_topk_merge_candidates(workspace, pl.tiles * k, M, k, out_idx, out_val, group, group_stride, stream);
 }

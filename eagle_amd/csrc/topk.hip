@@ -198,7 +198,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage1_f32_kernel(const float
 
 // K32 (every candidate index < 65536): the merge runs on 32-bit keys (16-bit monotone value | 0xffff - index), one DPP
 // reduction per selection round instead of the two of a 64-bit key.
-template <typename T, bool LSE, bool K32 = false>
+// CM = candidates per thread (CM * 256 >= ncand); x == nullptr: the values are rebuilt from the records' 16-bit keys (bf16 only;
+// -0 comes back as +0): the records then need not come from a logits array at all (eagle_lm_head_topk_rows_bf16)
+template <typename T, bool LSE, bool K32 = false, int CM = TK_CM>
 __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
                                                                 const T* __restrict__ x, int64_t ld,
                                                                 int64_t* __restrict__ out_idx, T* __restrict__ out_val,
@@ -210,10 +212,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
   const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
   if (K32) {
     // candidate c = value16 << 48 | (0xffffffff - index): with index < 65536 the low half is 0xffff0000 | (0xffff - index)
-    uint32_t key[TK_CM];
+    uint32_t key[CM];
     uint32_t best = 0;
 #pragma unroll
-    for (int i = 0; i < TK_CM; ++i) {
+    for (int i = 0; i < CM; ++i) {
       const int c = t + i * TK_THREADS;
       const unsigned long long v = c < ncand ? cand[(int64_t)row * ncand + c] : 0ull;
       key[i] = v ? ((uint32_t)(v >> 32) | ((uint32_t)v & 0xffffu)) : 0u;
@@ -225,29 +227,29 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
       if (bm != 0 && best == bm) {
         best = 0;
 #pragma unroll
-        for (int i = 0; i < TK_CM; ++i) {
+        for (int i = 0; i < CM; ++i) {
           if (key[i] == bm) key[i] = 0;
           best = key[i] > best ? key[i] : best;
         }
       }
     }
   } else {
-  unsigned long long key[TK_CM];
+  unsigned long long key[CM];
 #pragma unroll
-  for (int i = 0; i < TK_CM; ++i) {
+  for (int i = 0; i < CM; ++i) {
     const int c = t + i * TK_THREADS;
     key[i] = c < ncand ? cand[(int64_t)row * ncand + c] : 0ull;
   }
   unsigned long long best = 0;
 #pragma unroll
-  for (int i = 0; i < TK_CM; ++i) best = key[i] > best ? key[i] : best;
+  for (int i = 0; i < CM; ++i) best = key[i] > best ? key[i] : best;
   for (int r = 0; r < k; ++r) {
     const unsigned long long bm = wave_umax64(best);
     if (lane == 0) surv[wave * TK_MAXK + r] = bm;
     if (bm != 0 && best == bm) {
       best = 0;
 #pragma unroll
-      for (int i = 0; i < TK_CM; ++i) {
+      for (int i = 0; i < CM; ++i) {
         if (key[i] == bm) key[i] = 0;
         best = key[i] > best ? key[i] : best;
       }
@@ -292,7 +294,14 @@ __global__ __launch_bounds__(TK_THREADS) void topk_stage2_kernel(const unsigned 
     // output row: groups of out_group rows, out_gstride elements apart (out_group = 0: plain [rows, k])
     const int64_t opos = out_group ? (int64_t)(row / out_group) * out_gstride + (int64_t)(row % out_group) * k : (int64_t)row * k;
     out_idx[opos + lane] = idx;
-    if (out_val) out_val[opos + lane] = idx >= 0 ? x[(int64_t)row * ld + idx] : (T)0;
+    if (out_val) {
+      if (x) out_val[opos + lane] = idx >= 0 ? x[(int64_t)row * ld + idx] : (T)0;
+      else if (sizeof(T) == 2) {
+        const uint32_t k16 = (uint32_t)(won >> 48);
+        const uint32_t b = k16 == 0xffffu ? 0x7fc0u : (k16 & 0x8000u) ? (k16 & 0x7fffu) : (~k16 & 0xffffu);
+        out_val[opos + lane] = idx >= 0 ? (T)b : (T)0;
+      }
+    }
   }
 }
 
@@ -548,6 +557,24 @@ static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int 
   } else {
     return EAGLE_ERR_ARG;
   }
+  return eagle_check_launch();
+}
+
+// Stage 2 alone: rows x ncand candidate records (value key << 48 | 0xffffffff - index; 0 = empty) -> the k best of every row,
+// ids and bf16 values (rebuilt from the keys).  ncand <= 6144.  The records come from eagle_lm_head_topk_rows_bf16's GEMM
+// epilogue (or from any producer that keeps the record order: value first, then the lowest index).
+extern "C" int eagle_topk_merge_candidates(const void* cand, int ncand, int rows, int k, int64_t* out_idx, void* out_val,
+                                           int group, int64_t group_stride, hipStream_t stream) {
+  if (!cand || !out_idx) return EAGLE_ERR_ARG;
+  if (rows < 1 || ncand < 1 || ncand > TK_THREADS * 24 || k < 1 || k > TK_MAXK) return EAGLE_ERR_SHAPE;
+  if (group < 0 || (group > 0 && (rows % group || group_stride < (int64_t)group * k))) return EAGLE_ERR_SHAPE;
+#define TK_MERGE(CMV) hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false, false, CMV>), dim3(rows), dim3(TK_THREADS), 0, stream,      \
+    (const unsigned long long*)cand, ncand, k, (const bf16_t*)nullptr, (int64_t)0, out_idx, (bf16_t*)out_val, (const int64_t*)nullptr, \
+    (int64_t)0, (const float2*)nullptr, 0, (float*)nullptr, group, group_stride)
+  if (ncand <= TK_THREADS * 8) TK_MERGE(8);
+  else if (ncand <= TK_THREADS * 16) TK_MERGE(16);
+  else TK_MERGE(24);
+#undef TK_MERGE
   return eagle_check_launch();
 }
 

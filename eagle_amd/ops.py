@@ -480,6 +480,41 @@ def topk_into_table(logits: torch.Tensor, k: int, table_idx: torch.Tensor, table
          table_val.data_ptr() + row0 * k * 2, ptr(workspace), n, R * k, stream())
 
 
+def lm_head_topk_rows_ok(M: int, N: int, K: int, k: int) -> bool:
+    """True when lm_head_topk_into_table serves the shape (81..128 rows against a tall head)."""
+    return query("eagle_lm_head_topk_rows_workspace_bytes", M, N, K, k) > 0
+
+
+_head_ws_cache = {}
+
+
+def lm_head_topk_into_table(x: torch.Tensor, W: torch.Tensor, k: int, table_idx: torch.Tensor, table_val: torch.Tensor,
+                            row0: int, n: int, idx0: Optional[torch.Tensor] = None, M: Optional[int] = None) -> None:
+    """top-k(x[idx0] @ W^T) of M = B*n rows written into table[:, row0:row0+n, :] of the [B, R, k] tables, without the logits
+    (eagle_lm_head_topk_rows_bf16: candidates out of the GEMM's epilogue + the final merge)."""
+    _chk(x, "x"), _chk(W, "W")
+    N, K = W.shape
+    if M is None:
+        M = idx0.numel() if idx0 is not None else x.shape[0]
+    B, R, kk = table_idx.shape
+    if kk != k or M != B * n or not table_idx.is_contiguous() or not table_val.is_contiguous() or table_val.shape != table_idx.shape:
+        raise ValueError("lm_head_topk_into_table: tables [B, R, k] contiguous, M = B*n rows")
+    if x.stride(-1) != 1 or W.stride(1) != 1 or W.stride(0) != K or x.shape[-1] != K:
+        raise ValueError("x rows and W must be contiguous along K")
+    if idx0 is not None and (idx0.dtype != torch.int64 or not idx0.is_contiguous()):
+        raise TypeError("row index arrays must be contiguous int64")
+    need = query("eagle_lm_head_topk_rows_workspace_bytes", M, N, K, k)
+    if need <= 0:
+        raise ValueError("lm_head_topk_into_table: shape not served (see lm_head_topk_rows_ok)")
+    key = (x.device, torch.cuda.current_stream().cuda_stream)
+    ws = _head_ws_cache.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _head_ws_cache[key] = ws
+    call("eagle_lm_head_topk_rows_bf16", ptr(x), ptr(idx0), x.stride(0), None, 0, 0, ptr(W), K, None, M, N, K, k,
+         table_idx.data_ptr() + row0 * k * 8, table_val.data_ptr() + row0 * k * 2, n, R * k, ptr(ws), ws.numel(), stream())
+
+
 def first_argmax(logits: torch.Tensor) -> torch.Tensor:
     return topk(logits, 1, want_values=False)[1][:, 0]
 

@@ -59,6 +59,7 @@ class EagleDrafter:
         self.cap = (max_ctx + self.W + self.n_fwd + 255) // 256 * 256
         self.dev, self.D = dev, model.config.hidden_size
         self.wide_head_rows = 32      # lm_head row blocks from this many rows on take the MFMA GEMM (one weight pass)
+        self.head_topk_fused = True   # 81-128 rows: lm_head + top-k without the logits (eagle_lm_head_topk_rows_bf16)
         self.rows_head_max = 128      # ... and up to this many the row-batch weight stream (eagle_gemm_rows_bf16; 81..128 rows: its up-to-384-column form, 292 vs 345 us cold)
         # static bound on stable_len + tree rows handed to the attention launcher (grid size); a caller
         # that knows a tighter bound for the coming cycles may lower it (must stay >= the true length)
@@ -105,6 +106,11 @@ class EagleDrafter:
             # 17-32 rows (a 32-request batch at one row each): both 16-row tiles of x stay in registers of the weight-stream
             # kernel, which reads 2 KB of every weight row per block step (in-cycle 151936 x 4096: see DESIGN.md section 10)
             logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
+        elif self.B > 1 and self.head_topk_fused and self.D % 128 == 0 and \
+                ops.lm_head_topk_rows_ok(rows, self.lm_head.shape[0], self.D, self.k):
+            # 81-128 rows of a request batch against a tall head: candidates out of the GEMM's epilogue, no logits
+            ops.lm_head_topk_into_table(x, self.lm_head, self.k, self.flat_ids, self.flat_vals, row0, n, idx0=idx, M=rows)
+            return
         elif self.model.rows_min <= rows <= self.rows_head_max and self.D % 128 == 0:
             # decode batches: the row-batch weight stream (gather fused; 32 rows of the 151936-row head 257 vs 328 us on
             # the LDS-tiled kernels, tools/rows2_bench.py); past ~64 rows its x re-reads cost what the tiles' do

@@ -177,6 +177,24 @@ int eagle_topk_vocab(const void* logits, int64_t ld, int dtype, int rows, int V,
  * a20) without a copy pass per step.  rows % group == 0, group_stride >= group*k. */
 int eagle_topk_vocab_grouped(const void* logits, int64_t ld, int dtype, int rows, int V, int k, int64_t* out_idx,
                              void* out_val, void* workspace, int group, int64_t group_stride, eagle_stream_t stream);
+/* The final merge of the top-k alone: rows x ncand candidate records (bf16 monotone key << 48 | 0xffffffff - index; 0 = empty
+ * slot) -> every row's k best ids and bf16 values (rebuilt from the keys: -0 comes back as +0), optionally into a batched table
+ * as eagle_topk_vocab_grouped (group = 0: plain [rows, k]).  ncand <= 6144.  No reference line of its own: it is the second
+ * half of `torch.topk(logits, k)` for producers that never materialise the logits. */
+int eagle_topk_merge_candidates(const void* cand, int ncand, int rows, int k, int64_t* out_idx, void* out_val,
+                                int group, int64_t group_stride, eagle_stream_t stream);
+/* lm_head + top-k of a tree step of 81..128 rows over a tall head (N >= 32768) without the logits -- replaces
+ * `last_headout = lm_head(h)` followed by `torch.topk(last_headout, k)` of the expansion loop (SURVEY.md a11 + a20) for a
+ * request batch: the weight-stream GEMM (the 8-wave form of eagle_gemm_rows_bf16: x rows gathered through idx0 / ind0 as there,
+ * no second operand) rounds its outputs to bf16 and leaves k candidate records per (row, column tile) in `workspace`
+ * (eagle_lm_head_topk_rows_workspace_bytes(M, N, K, k) bytes, 8-byte aligned; 0 = shape not served: the call then returns
+ * EAGLE_ERR_SHAPE and the caller takes eagle_gemm_rows_bf16 + eagle_topk_vocab_grouped), eagle_topk_merge_candidates
+ * finishes.  Ids identical to that two-step path (same bf16 rounding, same order: value, then lowest index). */
+int64_t eagle_lm_head_topk_rows_workspace_bytes(int M, int N, int K, int k);
+int eagle_lm_head_topk_rows_bf16(const void* x0, const int64_t* idx0, int64_t ld0, const int64_t* ind0, int ind_n,
+                                 int64_t idx0_bstride, const void* W, int64_t ldw, const void* bias,
+                                 int M, int N, int K, int k, int64_t* out_idx, void* out_val, int group,
+                                 int64_t group_stride, void* workspace, int64_t workspace_bytes, eagle_stream_t stream);
 /* bf16 logits: the same top-k plus lse_out[rows] = fp32 log-sum-exp of every row out of the same pass over the logits
  * (stage 1 leaves a (max, sum-exp) pair per 1024-logit chunk, stage 2 merges them beside its final select) -- what
  * the dynamic tree's cumulative scores need (candidate probability = exp(logit - lse)) without a

@@ -90,6 +90,40 @@ def test_gemm_rows_wide_form_gathered_rows_and_switch():
     assert (y_wide.float() - y_narrow.float()).abs().max().item() <= 2 ** -5
 
 
+@pytest.mark.parametrize("B,n,N,K", [(32, 4, 151936, 4096), (32, 3, 70000, 256), (25, 5, 33000, 384), (128, 1, 40008, 128)])
+def test_lm_head_topk_without_logits(B, n, N, K):
+    """eagle_lm_head_topk_rows_bf16 (candidates out of the GEMM epilogue + the final merge) against the two-step path
+    (eagle_gemm_rows_bf16 + eagle_topk_vocab_grouped) on the same rows: identical ids -- bf16 logits over a big vocabulary are full
+    of ties -- and identical values, written into the same [B, R, k] table slots; gathered x rows; a planted all-equal row."""
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(B * n + N)
+    M, k, R = B * n, 10, 7
+    xs = torch.randn(M + 9, K, generator=g).to(BF).to(dev())
+    idx = torch.randperm(M + 9, generator=g)[:M].to(dev())
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(dev())
+    xs[idx[3]] = 0                                         # a row of all-zero logits: ids 0..9
+    assert ops.lm_head_topk_rows_ok(M, N, K, k)
+    ti = torch.full((B, R, k), -7, dtype=torch.int64, device=dev()); tv = torch.zeros((B, R, k), dtype=BF, device=dev())
+    ops.lm_head_topk_into_table(xs, W, k, ti, tv, 2, n, idx0=idx, M=M)
+    ri = torch.full((B, R, k), -7, dtype=torch.int64, device=dev()); rv = torch.zeros((B, R, k), dtype=BF, device=dev())
+    logits = ops.linear_rows(xs, W, idx0=idx, M=M)
+    ws = torch.empty(ops.query("eagle_topk_workspace_bytes", M, N, k), dtype=torch.uint8, device=dev())
+    ops.topk_into_table(logits, k, ri, rv, 2, n, ws)
+    assert torch.equal(ti, ri), "fused lm_head top-k ids differ from the two-step path"
+    assert torch.equal(tv, rv)
+    flat = ti[:, 2:2 + n].reshape(M, k)
+    assert flat[3].tolist() == list(range(10))
+    ev, ei = torch.topk(logits.float(), k, dim=1)          # values: the k largest logits of every row (ids may tie)
+    assert torch.equal(tv[:, 2:2 + n].reshape(M, k).float(), ev)
+
+
+def test_lm_head_topk_shapes_outside_the_wide_form_are_refused():
+    from eagle_amd import ops
+    assert not ops.lm_head_topk_rows_ok(32, 151936, 4096, 10)      # 32 rows: the register-resident stream's case
+    assert not ops.lm_head_topk_rows_ok(128, 4096, 4096, 10)       # a short head
+    assert not ops.lm_head_topk_rows_ok(128, 151936, 4000, 10)     # K % 128
+
+
 def test_gemm_rows_narrow_tiles_on_and_off():
     """3/4-width column tiles (picked where they fill whole rounds of resident workgroups) and full-width tiles: the same product,
     linear with bias + residual and SiLU*up, at 128 and 192 rows."""
