@@ -23,6 +23,7 @@
 // back with sc1 loads (past its own L1/L2, wherever the other slices ran), sums them in the same slice order and leaves
 // the counter at zero.  It is the slower of the two at these slab sizes (see g_rows_two_launch).
 #include "common.h"
+#include "topk_select.h"
 
 #define GR_NW 4                         // consumer waves per workgroup
 #define GR_COUNTER_BYTES 16384          // head of the workspace: one arrival counter per column tile (<= 4096 tiles split)
@@ -340,11 +341,6 @@ __global__ __launch_bounds__(GR_NW * 64) void gemm_rows_reduce_kernel(RowsArgs p
 #define GW_RT 3                         // most 16-column groups per wave
 template <int N> struct gw_int { static constexpr int value = N; };
 #define GW_KSTRIDE 800                  // bytes per row of the 16-bit key image (TOPK): 4 rows read side by side hit 4 x 8 banks
-__device__ __forceinline__ uint32_t gw_mono_bf16(bf16_t b) {          // topk.hip's monotone key (NaN largest, -0 == +0)
-  if ((b & 0x7fff) > 0x7f80) return 0xffffu;
-  if (b == 0x8000) b = 0;
-  return (b & 0x8000) ? (uint32_t)(uint16_t)~b : (uint32_t)(b | 0x8000);
-}
 // TOPK: no logits leave the kernel.  A tile's outputs are rounded to bf16, turned into 16-bit monotone keys and laid out in
 // LDS (the x buffers are free by then); every 16-lane group then selects the p.topk best of one row of the tile (lane l holds
 // columns l, l+16, ...: keys = value << 16 | 0xffff - column, the lowest column wins a tie) and writes them as candidate
@@ -488,7 +484,7 @@ __global__ __launch_bounds__(GW_NW * 64) void gemm_rows_wide_kernel(RowsArgs p) 
             const int n = gb * 16 + cb + r;
             float v = acc[mt][t][r];
             if (p.bias && n < p.N) v += bf2f(p.bias[n]);
-            k16[r] = n < p.N ? gw_mono_bf16(f2bf(v)) : 0u;
+            k16[r] = n < p.N ? tk_mono_bf16(f2bf(v)) : 0u;
           }
           *reinterpret_cast<uint2*>(xl + (mt * 16 + r16) * GW_KSTRIDE + 2 * cb) = make_uint2(k16[0] | (k16[1] << 16), k16[2] | (k16[3] << 16));
         }
@@ -537,65 +533,10 @@ __global__ __launch_bounds__(GW_NW * 64) void gemm_rows_wide_kernel(RowsArgs p) 
   __syncthreads();
   if (wave >= MT) return;                                  // 96-row form: waves 6 and 7 have no rows
   const int grp = lane >> 4, l16 = lane & 15;
-  // b1 >= b2 >= b3 >= b4 stay the four largest keys seen: one max and three medians per key
-  auto insert4 = [](uint32_t key, uint32_t& b1, uint32_t& b2, uint32_t& b3, uint32_t& b4) {
-    uint32_t n2, n3, n4;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n4) : "v"(b3), "v"(b4), "v"(key));
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n3) : "v"(b2), "v"(b3), "v"(key));
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(n2) : "v"(b1), "v"(b2), "v"(key));
-    b1 = key > b1 ? key : b1; b2 = n2; b3 = n3; b4 = n4;
-  };
-  auto group_umax = [](uint32_t v) {                        // the maximum of a 16-lane group, in every lane of the group
-    uint32_t t;
-    t = __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xf, 0xf, false); v = v > t ? v : t;   // quad_perm [1,0,3,2]
-    t = __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xf, 0xf, false); v = v > t ? v : t;   // quad_perm [2,3,0,1]
-    t = __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xf, 0xf, false); v = v > t ? v : t;  // row_half_mirror
-    t = __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xf, 0xf, false); v = v > t ? v : t;  // row_mirror
-    return v;
-  };
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int pass = 0; pass < 4; ++pass) {                   // (topk_select.h; the 16 slots after an odd group count hold key 0)
     const int R = 16 * wave + 4 * pass + grp;
-    const unsigned char* krow = xl + R * GW_KSTRIDE;
-    // Lane l of the group holds columns 32 jj + 2l and + 1 (one 4-byte read per pair, all reads issued before the first is
-    // used); its best FOUR keys below `limit` are kept (keys are distinct: the column is part of the key), so a lane only
-    // looks at its columns again after winning four rounds.  Columns past N and the 16 columns after the tile's last group
-    // hold key 0 (staged so): their 32-bit keys lie below every real one and a tile has >= 128 real columns.
-    auto scan = [&](auto limited, uint32_t limit, uint32_t& b1, uint32_t& b2, uint32_t& b3, uint32_t& b4) {
-      uint32_t w[GW_NW * GW_RT / 2];
-#pragma unroll
-      for (int jj = 0; jj < GW_NW * GW_RT / 2; ++jj)
-        w[jj] = *reinterpret_cast<const uint32_t*>(krow + 2 * (32 * jj + 2 * l16));   // unguarded: the row holds 400 slots
-      b1 = b2 = b3 = b4 = 0;
-#pragma unroll
-      for (int jj = 0; jj < GW_NW * GW_RT / 2; ++jj) {
-        if (32 * jj < 16 * ng) {                           // uniform
-          const uint32_t c = 32 * jj + 2 * l16;
-          uint32_t key0 = (w[jj] << 16) | (0xffffu - c);
-          uint32_t key1 = (w[jj] & 0xffff0000u) | (0xfffeu - c);
-          if (decltype(limited)::value) {
-            key0 = key0 < limit ? key0 : 0u;
-            key1 = key1 < limit ? key1 : 0u;
-          }
-          insert4(key0, b1, b2, b3, b4);
-          insert4(key1, b1, b2, b3, b4);
-        }
-      }
-    };
-    uint32_t b1, b2, b3, b4;
-    scan(gw_int<0>{}, 0u, b1, b2, b3, b4);
-    int wins = 0;
-    unsigned long long* out = p.cand + ((int64_t)R * p.tiles + tile) * p.topk;
-    for (int r = 0; r < p.topk; ++r) {
-      const uint32_t gm = group_umax(b1);
-      if (l16 == 0 && R < p.M) {
-        const uint32_t gidx = (uint32_t)(gb * 16) + (0xffffu - (gm & 0xffffu));
-        out[r] = (gm >> 16) ? (((unsigned long long)(gm & 0xffff0000u) << 32) | (unsigned long long)(0xffffffffu - gidx)) : 0ull;
-      }
-      if (gm != 0 && b1 == gm) {
-        b1 = b2; b2 = b3; b3 = b4; b4 = 0;
-        if (++wins == 4) { scan(gw_int<1>{}, gm, b1, b2, b3, b4); wins = 0; }   // its four known keys are spent: the rest of its columns
-      }
-    }
+    tk_select_group16<GW_NW * GW_RT / 2>(xl + R * GW_KSTRIDE, 16 * ng, (uint32_t)(gb * 16), p.topk,
+                                         p.cand + ((int64_t)R * p.tiles + tile) * p.topk, R < p.M, l16);
   }
 }
 

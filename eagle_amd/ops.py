@@ -497,7 +497,8 @@ def lm_head_topk_into_table(x: torch.Tensor, W: torch.Tensor, k: int, table_idx:
     if M is None:
         M = idx0.numel() if idx0 is not None else x.shape[0]
     B, R, kk = table_idx.shape
-    if kk != k or M != B * n or not table_idx.is_contiguous() or not table_val.is_contiguous() or table_val.shape != table_idx.shape:
+    if kk != k or M != B * n or row0 < 0 or row0 + n > R or not table_idx.is_contiguous() or not table_val.is_contiguous() or \
+            table_val.shape != table_idx.shape:
         raise ValueError("lm_head_topk_into_table: tables [B, R, k] contiguous, M = B*n rows")
     if x.stride(-1) != 1 or W.stride(1) != 1 or W.stride(0) != K or x.shape[-1] != K:
         raise ValueError("x rows and W must be contiguous along K")
