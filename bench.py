@@ -17,6 +17,10 @@ closed-loop recording pass with planted agreement so that acceptance lengths are
 the timed pass replays exactly that generation (and asserts it reproduces the same lengths).
 
 For N>1 every rank runs an independent replica (no data-path collective; "scaling": "weak").
+`--gpus N` with N > 1 and no torchrun environment (WORLD_SIZE unset) makes this process a LAUNCHER: before it touches a
+GPU it starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same
+flags>` as a child, passes rank 0's JSON line through and exits with the child's status; with fewer than N visible GPUs
+and the RCCL backend it refuses (exit 2).  Under torchrun (the driver's form for N > 1) it is a rank.
 The JSON line also carries `roofline` (the lm_head weight-streaming GEMM, the dominant kernel),
 `cpu_baseline` (the CPU oracle on the host cores, bounded sample) and `train` (draft-head
 training tokens/s, DP over the N ranks with RCCL all-reduce) when that path is available.
@@ -26,6 +30,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -39,7 +46,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achiev
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: WORLD_SIZE under torchrun, else 1)")
+    ap.add_argument("--repeats", type=int, default=4, help="extra timed passes of the same K steps (min / median / max reported)")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--ctx", type=int, default=300)
@@ -56,6 +64,35 @@ def parse():
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--plant", type=float, default=0.8, help="probability that the synthetic verifier agrees with a drafted child")
     return ap.parse_args()
+
+
+def launch_plan(gpus, env, n_visible: int, script: str, argv, port: int = 0):
+    """What `--gpus` asks of this process.  Returns None when it should run as a rank (single process, or already under
+    torchrun), else the command line of the launcher child.  Raises SystemExit(2) on a request that cannot be met.
+    Pure function of its arguments (tests/test_bench_launcher.py); nothing here touches a GPU."""
+    world_env = env.get("WORLD_SIZE")
+    if world_env is not None:
+        if gpus is not None and int(world_env) != gpus:
+            print(f"bench.py: --gpus {gpus} disagrees with WORLD_SIZE={world_env}", file=sys.stderr)
+            raise SystemExit(2)
+        return None
+    if gpus is None or gpus == 1:
+        return None
+    if gpus < 1:
+        print(f"bench.py: --gpus {gpus}: need at least one", file=sys.stderr)
+        raise SystemExit(2)
+    backend = env.get("EAGLE_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and n_visible < gpus:
+        print(f"bench.py: --gpus {gpus} needs {gpus} visible GPUs (found {n_visible}): one process per GPU over RCCL", file=sys.stderr)
+        raise SystemExit(2)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script] + list(argv)
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
 
 
 def make_model(cfg_name: str, dev, seed=0):
@@ -215,40 +252,127 @@ def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
             "timing": "HIP events around each in-cycle launch (eager, includes ~1-2 us of launch gap)"}
 
 
-def cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, expand, max_seconds=25.0):
-    """The CPU oracle (oracle/, 'port') on the same workload, bounded sample: prompt prefill +
-    expansion cycles until ~max_seconds.  Reported in the same unit as `value`."""
+def _timed_median(fn, warm: int = 3, timed: int = 5, cap_s: float = 40.0):
+    """BASELINE.md protocol: >= `warm` warm-up + >= `timed` timed iterations, median.  `cap_s` bounds the whole leg: when the
+    warm-up shows that the counts do not fit, fewer timed iterations run (never fewer than 3) and the caller's `sample`
+    says how many did."""
+    t0 = time.perf_counter()
+    for _ in range(warm):
+        fn()
+    per = (time.perf_counter() - t0) / warm
+    n = max(3, min(timed, int((cap_s - warm * per) / max(per, 1e-9))))
+    ts = []
+    for _ in range(n):
+        t1 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t1)
+    return statistics.median(ts), min(ts), max(ts), n
+
+
+def cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, expand):
+    """The CPU oracle (oracle/, 'port') on the headline workload: after the prompt prefill, draft/expansion cycles on the
+    host cores (catch-up forward + tree steps, each with lm_head + stable top-k), 3 warm-up + 5 timed cycles, median,
+    bf16 (`value`, the reference's arithmetic) and fp32.  Reported in the same unit as `value`."""
     from oracle import draft_model as dm
     from oracle import tree as ot
 
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     dims = dm.DraftDims(hidden=cfg.hidden_size, inter=cfg.intermediate_size, heads=cfg.num_attention_heads,
                         kv_heads=cfg.num_key_value_heads, vocab=cfg.vocab_size)
-    w = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    head = lm_head.cpu()
     tb = ot.generate_tree_buffers(expand=expand)
+    n_fw = 1 + len(tb.step_nodes)
+    res = {}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        w = {k: v.detach().cpu().to(dt) for k, v in model.state_dict().items()}
+        head = lm_head.cpu().to(dt)
 
-    def draft(h, ids, past_key_values=None, position_ids=None, tree_mask=None, use_cache=True):
-        return dm.forward(w, dims, h, ids, past_key_values=past_key_values, position_ids=position_ids,
-                          tree_mask=tree_mask, use_cache=True)
+        def draft(h, ids, past_key_values=None, position_ids=None, tree_mask=None, use_cache=True):
+            return dm.forward(w, dims, h, ids, past_key_values=past_key_values, position_ids=position_ids,
+                              tree_mask=tree_mask, use_cache=True)
 
-    hidden, tokens = prompt_hidden.cpu(), prompt_tokens.cpu()
+        hidden, tokens = prompt_hidden.cpu().to(dt), prompt_tokens.cpu()
+        g = torch.Generator().manual_seed(0)
+        state = {"tokens": tokens, "stable": None, "i": 0}
+        with torch.no_grad():
+            _, _, state["stable"], _ = ot.topk_generate(draft, head, tb, hidden, tokens, None)   # prompt prefill, untimed
+
+            def cycle():
+                n_acc = 1 + state["i"] % 3
+                state["i"] += 1
+                acc_h = torch.randn(1, n_acc, dims.hidden, generator=g).to(dt)
+                state["tokens"] = torch.cat([state["tokens"], torch.randint(0, dims.vocab, (1, n_acc), generator=g)], dim=1)
+                _, _, state["stable"], _ = ot.topk_generate(draft, head, tb, acc_h, state["tokens"], state["stable"])
+
+            med, lo, hi, n = _timed_median(cycle, cap_s=20.0)
+        res[name] = {"value": n_fw / med, "ms_per_cycle": {"median": med * 1e3, "min": lo * 1e3, "max": hi * 1e3}, "timed_cycles": n}
+        del w, head
+    return {"value": res["bf16"]["value"], "unit": "draft-tree steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"median of {res['bf16']['timed_cycles']} timed draft cycles ({n_fw} draft forwards + lm_head + stable top-k each) after 3 warm-up "
+                      f"cycles and a {prompt_hidden.shape[1]}-token prefill, bf16 torch CPU oracle, batch 1 (fp32 beside it)",
+            "bf16": res["bf16"], "fp32": res["fp32"]}
+
+
+def cpu_config0_baseline() -> dict:
+    """BASELINE.json configs[0] by BASELINE.md's protocol: EAGLE-1 draft head with resources/eagle_config.json dims, random
+    init, batch 1, L = 2048 synthetic tokens (the example conversation is ~2k tokens; no tokenizer on the box), forward +
+    loss (eagle/train.py:105-124) on the CPU oracle, no backward; >= 3 warm-up + >= 5 timed iterations, median; bf16 and
+    fp32.  tokens/s by the reference's definition (loss-masked tokens / wall time, eagle/train.py:140-141)."""
+    from oracle import draft_model as dm
+    from oracle import loss as ol
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    dims = dm.DraftDims()
+    w32 = dm.init_weights(dims, seed=0)
     g = torch.Generator().manual_seed(0)
-    with torch.no_grad():
-        ids, _, stable, _ = ot.topk_generate(draft, head, tb, hidden, tokens, None)   # prefill cycle (untimed warm-up)
-        n_fw, t0 = 0, time.perf_counter()
-        cycles = 0
-        while time.perf_counter() - t0 < max_seconds and cycles < 8:
-            n_acc = 1 + cycles % 3
-            acc_h = torch.randn(1, n_acc, dims.hidden, generator=g).to(torch.bfloat16)
-            tokens = torch.cat([tokens, torch.randint(0, dims.vocab, (1, n_acc), generator=g)], dim=1)
-            ids, _, stable, _ = ot.topk_generate(draft, head, tb, acc_h, tokens, stable)
-            n_fw += 1 + len(tb.step_nodes)
-            cycles += 1
-        dt = time.perf_counter() - t0
-    return {"value": n_fw / dt, "unit": "draft-tree steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{cycles} expansion cycles ({n_fw} draft forwards + lm_head + top-k) after a {hidden.shape[1]}-token prefill, "
-                      f"bf16 torch CPU oracle, batch 1, ctx~{hidden.shape[1]}"}
+    lm32 = torch.randn(dims.vocab, dims.hidden, generator=g) * 0.02
+    L = 2048
+    h32, t32 = torch.randn(1, L, dims.hidden, generator=g), torch.randn(1, L, dims.hidden, generator=g)
+    ids = torch.randint(0, dims.vocab, (1, L), generator=g)
+    mask = torch.ones(1, L, dtype=torch.int64)
+    out = {"unit": "loss tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+           "workload": "BASELINE configs[0]: llama2_7b-dims draft head, batch 1, L 2048, forward + loss, no backward"}
+    for name, dt in (("bf16", torch.bfloat16), ("fp32", torch.float32)):
+        w = {k: v.to(dt) for k, v in w32.items()}
+        lm, h, t = lm32.to(dt), h32.to(dt), t32.to(dt)
+
+        def it():
+            with torch.no_grad():
+                ol.eager_loss(dm.forward(w, dims, h, ids), t, lm, mask)
+
+        med, lo, hi, n = _timed_median(it, cap_s=45.0)
+        out[name] = {"value": L / med, "s_per_iter": {"median": med, "min": lo, "max": hi}, "timed_iters": n, "warmup_iters": 3}
+        del w, lm
+    out["value"] = out["bf16"]["value"]
+    out["sample"] = (f"median of {out['bf16']['timed_iters']} (bf16) / {out['fp32']['timed_iters']} (fp32) timed iterations after 3 warm-up, "
+                     "each one forward + loss over 2048 tokens")
+    return out
+
+
+def cpu_fused_loss_baseline(N: int = 2048, V: int = 151936, D: int = 4096) -> dict:
+    """The loss statements that follow the two lm_head products (eagle/train.py:108-123: softmax, log_softmax, agreement,
+    soft-label CE, smooth-L1) on the CPU oracle at the training shape N = 2048, V = 151936, from logits already in memory
+    -- the work the fused HIP loss kernels replace.  bf16 as the reference runs it; 3 warm-up + up to 5 timed, median,
+    bounded to ~40 s.  GB/s over the same algorithmic bytes as train.loss_roofline's forward (2*N*V*2 + 2*N*D*2)."""
+    from oracle import loss as ol
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    g = torch.Generator().manual_seed(5)
+    t_logits = (torch.randn(1, N, V, generator=g) * 2).to(torch.bfloat16)
+    o_logits = (torch.randn(1, N, V, generator=g) * 2).to(torch.bfloat16)
+    predict = torch.randn(1, N, D, generator=g).to(torch.bfloat16)
+    target = torch.randn(1, N, D, generator=g).to(torch.bfloat16)
+    mask = torch.ones(1, N, dtype=torch.int64)
+
+    def it():
+        with torch.no_grad():
+            ol.eager_loss_from_logits(t_logits, o_logits, predict, target, mask)
+
+    med, lo, hi, n = _timed_median(it, cap_s=40.0)
+    nbytes = 2.0 * N * V * 2 + 2.0 * N * D * 2
+    return {"value": nbytes / med / 1e9, "unit": "GB/s (algorithmic forward bytes)", "cores": torch.get_num_threads(), "kind": "port",
+            "s_per_iter": {"median": med, "min": lo, "max": hi}, "tokens_per_s": N / med,
+            "sample": f"median of {n} timed forward-loss passes after 3 warm-up, N {N} x V {V} bf16 logits resident in host memory, "
+                      "reference op order (oracle.loss.eager_loss_from_logits), no backward"}
 
 
 def batched_leg(dev, B=32, cycles=10, warm=3, plant_prob=0.8, seed=11):
@@ -417,6 +541,10 @@ def main():
     if os.environ.get("EAGLE_BENCH_TRACE"):          # rehearsal aid: dump every thread's stack if the run stalls
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["EAGLE_BENCH_TRACE"]), exit=True)
+    # device_count() does not initialise the GPU on this image; the launcher parent never does
+    cmd = launch_plan(a.gpus, os.environ, torch.cuda.device_count(), os.path.abspath(__file__), sys.argv[1:], free_port())
+    if cmd is not None:
+        raise SystemExit(subprocess.run(cmd).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -477,10 +605,21 @@ def main():
                                               per_graph=a.cycles_per_graph)
     if final != rec_final:
         raise SystemExit(f"timed replay diverged from the recorded generation: {final} vs {rec_final}")
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    # `value` comes from the pass above (W warm-up steps, then exactly K timed steps).  The same pass again `repeats`
+    # times (same prompt, same recorded verifier outputs, a fresh graph capture each) shows the run-to-run spread.
+    passes = [elapsed]
+    with torch.no_grad():
+        for _ in range(max(0, a.repeats)):
+            f2, _, e2 = run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, False, a.plant, tgt_kv, graph=not a.no_graph,
+                                   timed_from=a.warmup, timed_n=a.steps, sync=sync, per_graph=a.cycles_per_graph)
+            if f2 != rec_final:
+                raise SystemExit("a repeat of the timed replay diverged from the recorded generation")
+            passes.append(e2)
+    t = torch.tensor(passes, dtype=torch.float64, device=dev)
     if dist is not None:
         all_reduce_(t, dist.group.WORLD, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    passes = [float(x) for x in t.tolist()]
+    elapsed = passes[0]
     acc = torch.tensor([accepted, a.steps], dtype=torch.float64, device=dev)   # tokens per verify = accept_len + 1
     if dist is not None:
         all_reduce_(acc, dist.group.WORLD)
@@ -497,6 +636,12 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: {a.config} dims EAGLE-1 draft head, static 25-path tree depth 5 / top-k 10 "
                                f"({a.expand}), greedy verify, batch 1 per GPU, ctx {a.ctx}",
                    "draft_forwards_per_cycle": n_fw, "hip_graph": not a.no_graph, "replicas": world},
+        "draft_tree_steps_per_bench_step": n_fw,      # a bench "step" is one cycle: value = n_gpus * n_fw * 1000 / ms_per_step
+        "repeats": {"passes": len(passes), "ms_per_step": {"min": min(passes) / a.steps * 1e3,
+                                                           "median": statistics.median(passes) / a.steps * 1e3,
+                                                           "max": max(passes) / a.steps * 1e3},
+                    "value_median": world * a.steps * n_fw / statistics.median(passes),
+                    "note": "pass 0 (the one `value` is computed from) + `--repeats` more of the same K steps"},
         "cycles_per_s": world * a.steps / elapsed,
         "mean_accept_len": mean_accept,
         "mean_accept_len_note": f"synthetic verifier with planted agreement p={a.plant}; not a model-quality figure",
@@ -508,6 +653,7 @@ def main():
             drafter.prefill(prompt_hidden, prompt_tokens)
             out["roofline"] = roofline_lm_head(drafter, ver, tgt_kv, root, plen)
         if world == 1 and not a.no_cpu_baseline:
+            note("CPU baseline: draft cycles")
             out["cpu_baseline"] = cpu_baseline(cfg, model, lm_head, prompt_hidden, prompt_tokens, a.expand)
     del drafter, ver, tgt_kv, model, lm_head
     torch.cuda.empty_cache()
@@ -526,7 +672,10 @@ def main():
                                 micro_batch=a.train_micro_batch)
         if rank == 0 and tr is not None:
             if world == 1 and not a.no_cpu_baseline:
+                note("CPU baselines: training step sample, configs[0] forward + loss, fused loss")
                 tr["cpu_baseline"] = cpu_train_baseline()
+                tr["cpu_baseline"]["fused_loss"] = cpu_fused_loss_baseline()
+                out["cpu_baseline"]["config0"] = cpu_config0_baseline()
             out["train"] = tr
         note("training leg done")
     if rank == 0:

@@ -52,7 +52,8 @@ def make_eagle_batch(batch: Dict[str, torch.Tensor], verifier_hidden: torch.Tens
     batch["input_ids"][:, :max_model_len] (the verifier forward is the caller's).  hidden_states = verifier_hidden +
     U[low, high) noise; target[:, :-1] = hidden_states[:, 1:], last row zero (so the target is noisy too);
     input_ids shifted left with a trailing 0; loss_mask truncated, not shifted.  ``noise`` (already drawn) overrides
-    the device draw, for reproducible tests."""
+    the device draw, for reproducible tests.  The draw here is torch's (``torch.rand`` on the device under the caller's
+    ``generator``, as the reference's torch.rand_like); ``make_eagle_draft_input`` below draws Philox noise in-kernel."""
     dev = verifier_hidden.device
     ids = batch["input_ids"][:, :max_model_len].to(dev)
     lm = batch["loss_mask"][:, :max_model_len].to(dev)
@@ -68,15 +69,36 @@ def make_eagle_batch(batch: Dict[str, torch.Tensor], verifier_hidden: torch.Tens
     return {"input_ids": io, "hidden_states": ho, "target": tg, "loss_mask": lm}
 
 
+_noise_calls = 0     # Philox stream of the next make_eagle_draft_input call that is given no ``offset``
+
+
+def noise_state() -> int:
+    """The process-wide noise stream counter (save it with the trainer state; ``set_noise_state`` restores it on resume)."""
+    return _noise_calls
+
+
+def set_noise_state(n: int) -> None:
+    global _noise_calls
+    _noise_calls = int(n)
+
+
 def make_eagle_draft_input(batch: Dict[str, torch.Tensor], verifier_hidden: torch.Tensor, embed_weight: torch.Tensor,
                            max_model_len: int, transform_uniform_low: float = 0.0, transform_uniform_high: float = 0.0,
-                           seed: int = 0, offset: int = 0, want_noise: bool = False) -> Dict[str, torch.Tensor]:
+                           seed: int = 0, offset: Optional[int] = None, want_noise: bool = False) -> Dict[str, torch.Tensor]:
     """``make_eagle_batch`` fused with the draft head's embedding gather + concat: one kernel reads the verifier's hidden
-    state once, draws the uniform noise on the fly (Philox4x32-10 keyed by ``seed``; pass a fresh ``offset`` per
-    micro-batch, e.g. the global micro-batch counter), shifts, and writes the fc input ``x0`` [B*L, 2D] and the
-    (noisy) ``target`` directly -- no noise tensor, no hidden_states copy, no separate embed_concat pass
-    (eagle/train.py:256-275 + eagle/llama2.py:515, :537-542).  The result feeds ``EagleTrainer.step`` (which takes
-    ``x0`` in place of hidden_states / input_ids for the forward)."""
+    state once, draws the uniform noise on the fly (Philox4x32-10 keyed by ``seed``, stream ``offset``), shifts, and
+    writes the fc input ``x0`` [B*L, 2D] and the (noisy) ``target`` directly -- no noise tensor, no hidden_states copy,
+    no separate embed_concat pass (eagle/train.py:256-275 + eagle/llama2.py:515, :537-542).  The result feeds
+    ``EagleTrainer.step`` (which takes ``x0`` in place of hidden_states / input_ids for the forward).
+
+    The reference draws FRESH noise per call (torch.rand_like, eagle/train.py:272-275).  So does this: with ``offset``
+    left at None every call takes the next stream of a process-wide counter (``noise_state`` / ``set_noise_state`` for
+    checkpoint / resume; use a per-rank ``seed`` under data parallelism); an explicit ``offset`` reproduces one draw
+    (tests).  The stream used is returned as ``noise_offset``."""
+    global _noise_calls
+    if offset is None:
+        offset = _noise_calls
+        _noise_calls += 1
     dev = verifier_hidden.device
     ids = batch["input_ids"].to(dev)
     L = min(max_model_len, ids.shape[1], verifier_hidden.shape[1])
@@ -86,6 +108,7 @@ def make_eagle_draft_input(batch: Dict[str, torch.Tensor], verifier_hidden: torc
     x0, tg, io, noise = ops.eagle_input_embed_concat(verifier_hidden[:, :L], ids, embed_weight, transform_uniform_low,
                                                      transform_uniform_high, seed, offset, want_noise)
     out = {"input_ids": io, "x0": x0, "target": tg, "loss_mask": lm, "hidden_states": x0.view(ids.shape[0], L, -1)[:, :, x0.shape[1] // 2:]}
+    out["noise_offset"] = int(offset)
     if want_noise:
         out["noise"] = noise
     return out

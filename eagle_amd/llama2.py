@@ -278,6 +278,10 @@ class Llama2Model(nn.Module):
                 c.restart(past_len, self._rows_out[li])
                 self._rows_out[li] = min(self._rows_out[li], past_len)
                 return c
+        if past is None and c is not None and self._rows_out[li] == 0 and c.k.shape[0] == B and c.cap >= need and c.k.device == device:
+            # a fresh prompt while no view of the buffer is live (nothing was ever handed out, e.g. use_cache=False loops
+            # over validation batches): restart it in place -- no allocation, no memset
+            return c
         cap = max(need, getattr(self.config, "max_position_embeddings", 2048))
         nc = self.new_cache(B, cap, device)
         if past is not None:

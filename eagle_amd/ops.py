@@ -72,14 +72,27 @@ ROWS_MAX = 192   # rows one eagle_gemm_rows_bf16 call takes
 _rows_ws_cache = {}
 
 
+ROWS_COUNTER_BYTES = 16384   # GR_COUNTER_BYTES: the head of the workspace holds the per-tile arrival counters
+
+
 def _rows_workspace(nbytes: int, device) -> torch.Tensor:
-    """Workspace of eagle_gemm_rows_bf16, one per (device, stream): its head holds the per-tile arrival counters, which must
-    be zero on entry and are left zero by every call -- so the buffer is zero-filled once, when it is (re)allocated."""
+    """Workspace of eagle_gemm_rows_bf16, one per (device, stream).  Only its head (the per-tile arrival counters) must be
+    zero on entry, and every call leaves it zero -- so the buffer is allocated uninitialised and its first 16 KiB are
+    zeroed once, when it is (re)allocated.  Under stream capture nothing is allocated or zeroed: the capture reuses the
+    device's most recent workspace (the warm-up's; the capture stream is then its only user) and raises if there is none
+    that is large enough -- warm the call up before capturing it."""
     key = (device, torch.cuda.current_stream().cuda_stream)
     w = _rows_ws_cache.get(key)
-    if w is None or w.numel() < nbytes:
-        w = torch.zeros(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
-        _rows_ws_cache[key] = w
+    if w is not None and w.numel() >= nbytes:
+        return w
+    if torch.cuda.is_current_stream_capturing():
+        w = _rows_ws_cache.get((device, "last"))
+        if w is None or w.numel() < nbytes:
+            raise _hip.HipKernelError("eagle_gemm_rows_bf16 under stream capture needs its workspace from an earlier (warm-up) call")
+        return w
+    w = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+    w[:ROWS_COUNTER_BYTES].zero_()
+    _rows_ws_cache[key] = _rows_ws_cache[(device, "last")] = w
     return w
 
 
@@ -339,9 +352,13 @@ def eagle_input_embed_concat(hidden: torch.Tensor, ids: torch.Tensor, emb: torch
                              seed: int = 0, offset: int = 0, want_noise: bool = False):
     """Fused _make_eagle_input + embedding gather/concat (include/eagle_hip.h: eagle_input_embed_concat_bf16).
     hidden [B, L, D] bf16 (rows contiguous, any batch / row strides), ids [B, >= L] int64 unshifted.
+    emb [V, D] bf16, contiguous.  Token ids outside [0, V) are CLAMPED by the kernel (nn.Embedding, eagle/llama2.py:515,
+    faults on them instead): a tokenizer / vocabulary mismatch must be caught upstream of this call.
     Returns (x0 [B*L, 2D], target [B, L, D], ids_out [B, L], noise [B, L, D] or None)."""
     _chk(hidden, "hidden"), _chk(emb, "emb")
     B, L, D = hidden.shape
+    if emb.dim() != 2 or emb.shape[1] != D or not emb.is_contiguous():
+        raise ValueError(f"eagle_input_embed_concat: emb must be a contiguous [V, {D}] table (got {tuple(emb.shape)}, strides {emb.stride()})")
     if hidden.stride(2) != 1 or ids.dtype != torch.int64 or not ids.is_cuda or ids.stride(1) != 1 or ids.shape[0] != B or ids.shape[1] < L:
         raise ValueError("eagle_input_embed_concat: hidden [B, L, D] with contiguous rows, ids [B, >= L] int64 on the device")
     dev = hidden.device

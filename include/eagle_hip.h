@@ -378,7 +378,8 @@ int eagle_make_eagle_input_bf16(const void* hidden, const void* noise, const int
  *             high == low: no noise.  The reference draws it in the hidden state's dtype and adds it in that dtype (:272-275).
  *   x0      [B*L, 2D] = cat(embed_tokens[ids shifted left, trailing 0], hidden + noise): the input of the fc GEMM
  *   target  [B*L, D]: target[:, :-1] = (hidden + noise)[:, 1:], last row of every sequence 0 (the target is noisy too)
- *   ids_out [B*L] (may be NULL) = ids shifted left with trailing 0 (:266-268). */
+ *   ids_out [B*L] (may be NULL) = ids shifted left with trailing 0 (:266-268).
+ * embed [V, D] contiguous.  Ids outside [0, V) are clamped into it (nn.Embedding faults on them): validate upstream. */
 int eagle_input_embed_concat_bf16(const void* hidden, int64_t ldh_b, int64_t ldh_l, const int64_t* ids, int64_t ldi,
                                   const void* emb, int V, float low, float high, uint64_t seed, uint64_t offset,
                                   void* x0, void* target, int64_t* ids_out, void* noise_out, int B, int L, int D,

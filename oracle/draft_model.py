@@ -144,14 +144,12 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
     return w * xf.to(dt)
 
 
-def attention(x, w, dims: DraftDims, mask, position_ids, past, use_cache, cos, sin):
-    # eagle/llama2.py:193-285
-    B, q_len, _ = x.shape
-    H, HK, hd = dims.heads, dims.kv_heads, dims.head_dim
-    p = "layers.0.self_attn."
-    q = F.linear(x, w[p + "q_proj.weight"]).view(B, q_len, H, hd).transpose(1, 2)
-    k = F.linear(x, w[p + "k_proj.weight"]).view(B, q_len, HK, hd).transpose(1, 2)
-    v = F.linear(x, w[p + "v_proj.weight"]).view(B, q_len, HK, hd).transpose(1, 2)
+def attention_core(q, k, v, dims: DraftDims, mask, position_ids, past, use_cache, cos, sin):
+    """eagle/llama2.py:226-273 from the projected (pre-RoPE) q [B,H,q,hd], k / v [B,HK,q,hd] on: RoPE at
+    ``position_ids``, cache concat, repeat_kv, scores / sqrt(hd) + mask, fp32 softmax cast back to the query dtype,
+    P.V.  Returns (o [B,q,H*hd] before o_proj, present)."""
+    B, H, q_len, hd = q.shape
+    HK = k.shape[1]
     q, k = apply_rope(q, k, cos.to(v.dtype), sin.to(v.dtype), position_ids)
     if past is not None:
         k = torch.cat([past[0], k], dim=2)
@@ -165,7 +163,19 @@ def attention(x, w, dims: DraftDims, mask, position_ids, past, use_cache, cos, s
     if mask is not None:
         s = s + mask
     pr = F.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
-    o = torch.matmul(pr, v).transpose(1, 2).contiguous().reshape(B, q_len, dims.hidden)
+    o = torch.matmul(pr, v).transpose(1, 2).contiguous().reshape(B, q_len, H * hd)
+    return o, present
+
+
+def attention(x, w, dims: DraftDims, mask, position_ids, past, use_cache, cos, sin):
+    # eagle/llama2.py:193-285
+    B, q_len, _ = x.shape
+    H, HK, hd = dims.heads, dims.kv_heads, dims.head_dim
+    p = "layers.0.self_attn."
+    q = F.linear(x, w[p + "q_proj.weight"]).view(B, q_len, H, hd).transpose(1, 2)
+    k = F.linear(x, w[p + "k_proj.weight"]).view(B, q_len, HK, hd).transpose(1, 2)
+    v = F.linear(x, w[p + "v_proj.weight"]).view(B, q_len, HK, hd).transpose(1, 2)
+    o, present = attention_core(q, k, v, dims, mask, position_ids, past, use_cache, cos, sin)
     return F.linear(o, w[p + "o_proj.weight"]), present
 
 

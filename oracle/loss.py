@@ -25,8 +25,16 @@ def eager_loss(predict: torch.Tensor, target: torch.Tensor, lm_head_w: torch.Ten
     hd = lm_head_w.dtype
     with torch.no_grad():
         target_head = F.linear(target.to(hd), lm_head_w)
-        target_p = torch.softmax(target_head, dim=2).detach()
     out_head = F.linear(predict.to(hd), lm_head_w)
+    return eager_loss_from_logits(target_head, out_head, predict, target, loss_mask, v_w, p_w)
+
+
+def eager_loss_from_logits(target_head: torch.Tensor, out_head: torch.Tensor, predict: torch.Tensor, target: torch.Tensor,
+                           loss_mask: torch.Tensor, v_w: float = 1.0, p_w: float = 0.1) -> Dict[str, torch.Tensor]:
+    """The statements of train.py:108-123 that follow the two lm_head products (what the fused loss kernels replace):
+    softmax, log_softmax, agreement count, soft-label CE, smooth-L1, weighted sum -- in the reference's op order."""
+    with torch.no_grad():
+        target_p = torch.softmax(target_head, dim=2).detach()
     out_logp = torch.log_softmax(out_head, dim=2)
     m3 = loss_mask[:, :, None]
     _, t_tok = torch.max(target_p, 2)

@@ -177,7 +177,8 @@ DraftFn = Callable[..., Tuple[torch.Tensor, tuple]]
 
 
 def topk_generate(draft_fn: DraftFn, lm_head_w: torch.Tensor, tb: TreeBuffers,
-                  hidden_states: torch.Tensor, input_ids: torch.Tensor, stable_kv=None, head_fn=None):
+                  hidden_states: torch.Tensor, input_ids: torch.Tensor, stable_kv=None, head_fn=None,
+                  forced_ids: Optional[torch.Tensor] = None):
     """The expansion loop (upstream cnets.py ``topK_genrate``, greedy branch).
 
     hidden_states [1, n_new, D]: target hidden states of the tokens not yet in ``stable_kv``.
@@ -187,6 +188,10 @@ def topk_generate(draft_fn: DraftFn, lm_head_w: torch.Tensor, tb: TreeBuffers,
       -> (out_hidden, kv).
     head_fn(hidden [rows, D]) -> logits [rows, V]; default: the frozen lm_head as a bias-free
       Linear (eagle/train.py:215-228).
+    forced_ids [1+n_fwd, k] (tests only): the tokens fed to the next step are taken from this table instead of
+      from the loop's own top-k, so that a second implementation whose logits differ by a rounding can be followed
+      row by row without the two expansions drifting apart; the returned ids / values / logits are still the
+      loop's own.
     Returns (flat_topk_ids [1+n_fwd, k], flat_topk_vals, new_stable_kv, debug dict).
     """
     if head_fn is None:
@@ -199,12 +204,16 @@ def topk_generate(draft_fn: DraftFn, lm_head_w: torch.Tensor, tb: TreeBuffers,
                               position_ids=None, tree_mask=None, use_cache=True)
     new_stable = kv
     logits = head_fn(out_hidden[:, -1])  # [1,V]
-    all_ids, all_vals, step_inputs = [], [], []
+    all_ids, all_vals, step_inputs, all_logits = [], [], [], []
+    row = 0
     for d in range(len(tb.step_nodes)):
         vals, idx = stable_topk(logits, tb.topk)
         all_ids.append(idx)
         all_vals.append(vals)
-        sel = idx.reshape(-1)[tb.step_tree_indices[d]]
+        all_logits.append(logits)
+        feed = idx if forced_ids is None else forced_ids[row: row + idx.shape[0]].to(idx.dtype)
+        row += idx.shape[0]
+        sel = feed.reshape(-1)[tb.step_tree_indices[d]]
         src = out_hidden[:, -1:] if d == 0 else out_hidden
         hid = src[:, tb.step_parent_row[d]]
         pos = len_posi + tb.step_position_ids[d]
@@ -216,7 +225,8 @@ def topk_generate(draft_fn: DraftFn, lm_head_w: torch.Tensor, tb: TreeBuffers,
     vals, idx = stable_topk(logits, tb.topk)
     all_ids.append(idx)
     all_vals.append(vals)
-    return torch.cat(all_ids), torch.cat(all_vals), new_stable, {"steps": step_inputs}
+    all_logits.append(logits)
+    return torch.cat(all_ids), torch.cat(all_vals), new_stable, {"steps": step_inputs, "logits": torch.cat(all_logits)}
 
 
 def tree_candidates(root_token: int, flat_topk_ids: torch.Tensor, tb: TreeBuffers):

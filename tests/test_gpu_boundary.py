@@ -158,6 +158,29 @@ def test_stale_kv_view_raises_and_a_clone_survives():
         _close(o2b, rb, what="continuation of the short branch")
 
 
+def test_forward_without_cache_reuses_its_buffer_and_views_still_survive():
+    """A loop of forward() calls that hand out no cache views (use_cache=False: validation batches) restarts one KV buffer
+    in place -- same storage, right answers -- while a view handed out by use_cache=True still gets a fresh buffer on the
+    next prompt (the reference's independent torch.cat results)."""
+    m, wb, dims = _tiny_model()
+    g = torch.Generator().manual_seed(23)
+    d = DEV
+    ptrs = set()
+    with torch.no_grad():
+        for L in (7, 12, 3):
+            h, i = torch.randn(2, L, dims.hidden, generator=g).to(BF), torch.randint(0, dims.vocab, (2, L), generator=g)
+            _close(m(h.to(d), i.to(d)), dm.forward(wb, dims, h, i), what=f"no-cache forward L={L}")
+            ptrs.add(m._caches[0].k.data_ptr())
+        assert len(ptrs) == 1, "forward(use_cache=False) allocated a new KV buffer per call"
+        h, i = torch.randn(2, 5, dims.hidden, generator=g).to(BF), torch.randint(0, dims.vocab, (2, 5), generator=g)
+        o, kv = m(h.to(d), i.to(d), use_cache=True)                     # reuses the buffer too, then hands out a view of it
+        assert kv[0][0].data_ptr() in ptrs
+        k_before = kv[0][0].clone()
+        h2, i2 = torch.randn(2, 9, dims.hidden, generator=g).to(BF), torch.randint(0, dims.vocab, (2, 9), generator=g)
+        m(h2.to(d), i2.to(d))                                           # a fresh prompt while the view is out: new buffer
+        assert m._caches[0].k.data_ptr() not in ptrs and torch.equal(kv[0][0], k_before)
+
+
 # ------------------------------------------------------------------ derived weights across optimizer steps
 def test_eval_forward_after_trainer_step_uses_the_updated_weights():
     """EagleTrainer's fused AdamW writes the parameters through raw pointers (no Tensor._version bump): the decode

@@ -439,6 +439,16 @@ def test_fused_eagle_input_matches_oracle_and_philox():
     out2 = data.make_eagle_draft_input({"input_ids": ids, "loss_mask": mask}, hid.to(DEV), emb.to(DEV), max_len, low, high, seed=seed, offset=8,
                                        want_noise=True)
     assert not torch.equal(out2["noise"], out["noise"])
+    # no offset given: every call draws a fresh stream (the reference's torch.rand_like per call, eagle/train.py:272-275),
+    # and the counter is restorable for resume
+    data.set_noise_state(100)
+    a = data.make_eagle_draft_input({"input_ids": ids, "loss_mask": mask}, hid.to(DEV), emb.to(DEV), max_len, low, high, seed=seed, want_noise=True)
+    b = data.make_eagle_draft_input({"input_ids": ids, "loss_mask": mask}, hid.to(DEV), emb.to(DEV), max_len, low, high, seed=seed, want_noise=True)
+    assert (a["noise_offset"], b["noise_offset"], data.noise_state()) == (100, 101, 102)
+    assert not torch.equal(a["noise"], b["noise"]) and not torch.equal(a["target"], b["target"])
+    data.set_noise_state(100)
+    a2 = data.make_eagle_draft_input({"input_ids": ids, "loss_mask": mask}, hid.to(DEV), emb.to(DEV), max_len, low, high, seed=seed, want_noise=True)
+    assert torch.equal(a2["noise"], a["noise"]) and torch.equal(a2["x0"], a["x0"])
 
 
 def test_trainer_step_from_the_fused_input_equals_the_two_pass_input():

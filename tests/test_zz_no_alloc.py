@@ -24,6 +24,16 @@ def _both(logits, k):
               None, rows, _hip.stream())
     assert torch.cuda.memory_allocated() <= before     # nothing was allocated through torch either
     torch.cuda.synchronize()
+    # ... nor behind torch's back: once the scratch array's address is resolved (the call above), another call must leave
+    # the device's free memory as it is (torch.cuda.memory_allocated cannot see a hipMalloc made inside the library)
+    i2, v2 = torch.full_like(i1, -7), torch.zeros_like(v1)
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    _hip.call("eagle_topk_vocab_noalloc", _hip.ptr(logits), logits.stride(0), dt, rows, V, k, _hip.ptr(i2), _hip.ptr(v2),
+              None, rows, _hip.stream())
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before, "eagle_topk_vocab_noalloc changed the device's free memory"
+    assert torch.equal(i2, i1) and torch.equal(v2, v1)
     return i0, v0, i1, v1
 
 
