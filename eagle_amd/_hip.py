@@ -30,6 +30,8 @@ class HipKernelError(RuntimeError):
 P, I, L, F = c_void_p, c_int, c_int64, c_float
 SIGNATURES = {
     "eagle_gemm_skinny_bf16": (I, [P, P, L, I, P, I, L, F, P, P, L, P, P, P, P, L, P, L, I, I, I, I, P]),
+    "eagle_packed_weight_bytes": (L, [I, I]),
+    "eagle_pack_weight_bf16": (I, [P, L, I, I, P, P]),
     "eagle_gemm_rows_workspace_bytes": (L, [I, I, I, I]),
     "eagle_gemm_rows_bf16": (I, [P, P, L, I, P, I, L, P, P, L, P, P, L, P, P, L, P, L, I, I, I, I, P, L, P]),
     "eagle_gemm_nt_bf16": (I, [P, L, P, L, P, L, P, P, L, I, I, I, I, I, P]),

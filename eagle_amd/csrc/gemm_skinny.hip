@@ -14,6 +14,12 @@
 //     the epilogue (bias, residual add, SiLU*up) runs in the producing kernel.
 //   * the activation row can be the concatenation of two gathered sources:
 //     fc(cat(embed_tokens[ids], hidden[parent_row]))  (eagle/llama2.py:515, :542).
+//   * PACKED weights (eagle_pack_weight_bf16, round 3): the fragment shape above reads 16 rows x 64 B per wave-instruction,
+//     i.e. HALF cache lines whose other half follows with the next instruction.  Measured on MI355X (tools/stream_probe.hip,
+//     262 MB from cold caches, non-temporal): that shape streams at 5.4 TB/s, wave-instructions that read 1 KiB contiguous
+//     at 6.3 TB/s (+17 %).  A packed copy of W stores every 16-row x 32-k fragment as ONE contiguous 1 KiB block in lane order
+//     ([N/16][K/32][64 lanes][8 bf16]), so the same registers are filled by whole-line reads; the arithmetic (and therefore
+//     every output bit) is unchanged.
 #include "common.h"
 
 #define SK_WAVES 8
@@ -32,9 +38,16 @@ struct SkinnyArgs {
   bool nt;                                               // host-side only: stream W with non-temporal loads
   int rot;                                               // keepx: neighbouring blocks walk their K super-steps from staggered starts
   int stage;                                             // keepx: collect a block's outputs in LDS and write them when its stream is done
+  int packed;                                            // host-side only: W / W2 are eagle_pack_weight_bf16 images
 };
 
-template <int RT, int MT, int EPI>
+// Packed image: tile T = rows [16T, 16T+16), k-block f = columns [32f, 32f+32): 512 elements at (T * K/32 + f) * 512, lane
+// l = r16 + 16 g holds W[16T + r16][32f + 8g .. +8].  Rows past N are zero.  Address of lane `lane`'s piece of (T, k):
+__device__ __forceinline__ const bf16_t* sk_pk(const bf16_t* base, int T, int K, int k, int lane) {
+  return base + ((int64_t)T * (K >> 5) + (k >> 5)) * 512 + lane * 8;
+}
+
+template <int RT, int MT, int EPI, bool PK = false>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
   constexpr int NT = RT * MT;
   __shared__ __attribute__((aligned(16))) float red[SK_WAVES][NT][64][4];
@@ -50,8 +63,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
     int n = n0 + ((EPI == EPI_SILU_MUL) ? 0 : t * 16) + r16;
     n = n < p.N ? n : p.N - 1;  // clamp: rows past N are computed on valid memory and dropped
     const bf16_t* base = (EPI == EPI_SILU_MUL && t == 1) ? p.W2 : p.W;
-    wrow[t] = base + (int64_t)n * p.K + 8 * g;
+    if (PK) {                                           // whole tiles: the image is zero-padded to 16 rows
+      const int T = min((n0 + ((EPI == EPI_SILU_MUL) ? 0 : t * 16)) >> 4, (p.N - 1) >> 4);
+      wrow[t] = sk_pk(base, T, p.K, 0, lane);
+    } else {
+      wrow[t] = base + (int64_t)n * p.K + 8 * g;
+    }
   }
+  constexpr int KS = PK ? 16 : 1;                       // element step per k: a packed k-block of 32 columns is 512 elements on
   const bf16_t* xa[MT];
   const bf16_t* xb[MT];
   bool mvalid[MT];
@@ -87,7 +106,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
     for (int s = 0; s < 4; ++s) {
       const int k = kb + s * 32;
 #pragma unroll
-      for (int t = 0; t < RT; ++t) a[s][t] = *reinterpret_cast<const bf16x8*>(wrow[t] + k);
+      for (int t = 0; t < RT; ++t) a[s][t] = *reinterpret_cast<const bf16x8*>(wrow[t] + k * KS);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const bf16_t* src = (k < p.K0) ? xa[mt] : xb[mt];
@@ -118,7 +137,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
       const int k = (nfull << 7) + s * 32;
       bf16x8 a[RT], b[MT];
 #pragma unroll
-      for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const bf16x8*>(wrow[t] + k);
+      for (int t = 0; t < RT; ++t) a[t] = *reinterpret_cast<const bf16x8*>(wrow[t] + k * KS);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const bf16_t* src = (k < p.K0) ? xa[mt] : xb[mt];
@@ -240,7 +259,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p
 // ---------------------------------------------------------------------------------------------
 template <int RT> struct SkStage { bf16x8 a[4][RT]; bf16x8 b[4]; };
 
-template <int RT, int EPI, bool NT>
+template <int RT, int EPI, bool NT, bool PK = false>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(SkinnyArgs p, int rows_per_block, int n_iter) {
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;   // distinct 16-row groups per tile-step
   constexpr int RPS = RTW * 16;                               // output rows per tile-step
@@ -268,13 +287,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
     const int kb = (wave + SK_WAVES * it) << 7;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-      int n = row_lo + ts * RPS + ((EPI == EPI_SILU_MUL) ? (t >> 1) : t) * 16 + r16;
+      const int nb = row_lo + ts * RPS + ((EPI == EPI_SILU_MUL) ? (t >> 1) : t) * 16;
+      int n = nb + r16;
       n = n < row_hi ? n : row_hi - 1;
       const bf16_t* base = (EPI == EPI_SILU_MUL && (t & 1)) ? p.W2 : p.W;
-      const bf16_t* wp = base + (int64_t)n * p.K + 8 * g + kb;
+      // packed: row_lo is a multiple of 16 (launcher); tiles past the block's last one re-read it
+      const bf16_t* wp = PK ? sk_pk(base, min(nb >> 4, (row_hi - 1) >> 4), p.K, kb, lane) : base + (int64_t)n * p.K + 8 * g + kb;
+      constexpr int SS = PK ? 512 : 32;
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        st.a[s][t] = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * 32)) : *reinterpret_cast<const bf16x8*>(wp + s * 32);
+        st.a[s][t] = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * SS)) : *reinterpret_cast<const bf16x8*>(wp + s * SS);
     }
   };
   auto load_x = [&](SkStage<RT>& st, int it) {
@@ -436,7 +458,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
 // MT = 16-row activation tiles whose fragments stay in registers (1: <= 16 rows, every tree step of one request; 2: <= 32
 // rows, a 32-request batch at one row each -- each weight fragment then feeds two MFMAs instead of one).
 #define SK_OST_COLS 640
-template <int RT, int EPI, int NI, bool NT, int S = 2, int MT = 1, bool STAGE = false>
+template <int RT, int EPI, int NI, bool NT, int S = 2, int MT = 1, bool STAGE = false, bool PK = false>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
   static_assert(NI % S == 0, "S register stages rotate through the NI super-steps of a tile-step");
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;
@@ -471,13 +493,15 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
     const int kb = (wave + SK_WAVES * ((it + rot) & (NI - 1))) << 7;
 #pragma unroll
     for (int t = 0; t < RT; ++t) {
-      int n = row_lo + ts * RPS + ((EPI == EPI_SILU_MUL) ? (t >> 1) : t) * 16 + r16;
+      const int nb = row_lo + ts * RPS + ((EPI == EPI_SILU_MUL) ? (t >> 1) : t) * 16;
+      int n = nb + r16;
       n = n < row_hi ? n : row_hi - 1;             // see gemm_skinny_stream_kernel: no predicated loads
       const bf16_t* base = (EPI == EPI_SILU_MUL && (t & 1)) ? p.W2 : p.W;
-      const bf16_t* wp = base + (int64_t)n * p.K + 8 * g + kb;
+      const bf16_t* wp = PK ? sk_pk(base, min(nb >> 4, (row_hi - 1) >> 4), p.K, kb, lane) : base + (int64_t)n * p.K + 8 * g + kb;
+      constexpr int SS = PK ? 512 : 32;
 #pragma unroll
       for (int s = 0; s < 4; ++s)
-        st[s][t] = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * 32)) : *reinterpret_cast<const bf16x8*>(wp + s * 32);
+        st[s][t] = NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp + s * SS)) : *reinterpret_cast<const bf16x8*>(wp + s * SS);
     }
   };
 #pragma unroll
@@ -659,17 +683,18 @@ static int sk_num_cus() {
 // cache); those are read with the default policy, every other weight with non-temporal loads so that it does not
 // displace them.  No state is kept in the library.
 #define EAGLE_GEMM_KEEP_RESIDENT 0x100
+#define EAGLE_GEMM_W_PACKED 0x200
 static bool sk_stream_nt(const SkinnyArgs& a, int epi) { (void)epi; return a.nt; }
 
-template <int RT, int EPI, int MT = 1>
-static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
+template <int RT, int EPI, int MT, bool PK>
+static int launch_skinny_keepx_(const SkinnyArgs& a, hipStream_t st) {
   int grid = sk_num_cus() * g_sk_keepx_bpc;
   int R = (a.N + grid - 1) / grid;
   if (R < 16) R = 16;
-  R = (R + 7) & ~7;                                    // 16-byte runs when the staged outputs are copied out
+  R = PK ? ((R + 15) & ~15) : ((R + 7) & ~7);          // 16-byte runs when the staged outputs are copied out; packed: whole 16-row tiles
   grid = (a.N + R - 1) / R;
   const bool nt = sk_stream_nt(a, EPI);
-  if constexpr (MT == 1) {
+  if constexpr (MT == 1 && !PK) {
     if (g_sk_keepx_stages == 4) {
       if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
       else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 4>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
@@ -677,40 +702,80 @@ static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
     }
   }
   if (a.stage) {                                       // the instantiation that collects its outputs in LDS (see the kernel)
-    if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 2, MT, true>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
-    else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 2, MT, true>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+    if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 2, MT, true, PK>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+    else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 2, MT, true, PK>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
     return eagle_check_launch();
   }
-  if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 2, MT>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
-  else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 2, MT>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, true, 2, MT, false, PK>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
+  else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<RT, EPI, 4, false, 2, MT, false, PK>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);
   return eagle_check_launch();
 }
+template <int RT, int EPI, int MT = 1>
+static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
+  return a.packed ? launch_skinny_keepx_<RT, EPI, MT, true>(a, st) : launch_skinny_keepx_<RT, EPI, MT, false>(a, st);
+}
 
-template <int RT, int EPI>
-static int launch_skinny_stream(const SkinnyArgs& a, hipStream_t st) {
-  constexpr int RPS = ((EPI == EPI_SILU_MUL) ? RT / 2 : RT) * 16;
+template <int RT, int EPI, bool PK>
+static int launch_skinny_stream_(const SkinnyArgs& a, hipStream_t st) {
   static int occ = 0;                                  // resident 512-thread blocks per CU for this instantiation
   if (!occ) {
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_skinny_stream_kernel<RT, EPI, true>, SK_WAVES * 64, 0) != hipSuccess || occ < 1) occ = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, gemm_skinny_stream_kernel<RT, EPI, true, PK>, SK_WAVES * 64, 0) != hipSuccess || occ < 1) occ = 1;
   }
   int grid = sk_num_cus() * (occ < g_sk_blocks_per_cu ? occ : g_sk_blocks_per_cu);
   int R = (a.N + grid - 1) / grid;
   if (R < g_sk_min_rows) R = g_sk_min_rows;            // few rows per block waste MFMA lanes, not bandwidth
-  R = (R + 3) & ~3;                                    // keeps the 8-byte output stores aligned
+  R = PK ? ((R + 15) & ~15) : ((R + 3) & ~3);          // keeps the 8-byte output stores aligned; packed: whole 16-row tiles
   grid = (a.N + R - 1) / R;
   const int nfull = (a.K + 127) >> 7;
   const int n_iter = (nfull + SK_WAVES - 1) / SK_WAVES;
-  (void)RPS;
-  if (sk_stream_nt(a, EPI)) hipLaunchKernelGGL((gemm_skinny_stream_kernel<RT, EPI, true>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R, n_iter);
-  else hipLaunchKernelGGL((gemm_skinny_stream_kernel<RT, EPI, false>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R, n_iter);
+  if (sk_stream_nt(a, EPI)) hipLaunchKernelGGL((gemm_skinny_stream_kernel<RT, EPI, true, PK>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R, n_iter);
+  else hipLaunchKernelGGL((gemm_skinny_stream_kernel<RT, EPI, false, PK>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R, n_iter);
   return eagle_check_launch();
+}
+template <int RT, int EPI>
+static int launch_skinny_stream(const SkinnyArgs& a, hipStream_t st) {
+  return a.packed ? launch_skinny_stream_<RT, EPI, true>(a, st) : launch_skinny_stream_<RT, EPI, false>(a, st);
 }
 
 template <int RT, int MT, int EPI>
 static int launch_skinny(const SkinnyArgs& a, hipStream_t st) {
   const int rows_per_block = (EPI == EPI_SILU_MUL) ? 16 : RT * 16;
   dim3 grid((a.N + rows_per_block - 1) / rows_per_block), block(SK_WAVES * 64);
-  hipLaunchKernelGGL((gemm_skinny_kernel<RT, MT, EPI>), grid, block, 0, st, a);
+  if (a.packed) hipLaunchKernelGGL((gemm_skinny_kernel<RT, MT, EPI, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((gemm_skinny_kernel<RT, MT, EPI, false>), grid, block, 0, st, a);
+  return eagle_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// eagle_pack_weight_bf16: the packed image of W [N, K] (row stride ldw) -- see the head of this file.  One 16-byte piece per
+// thread; run once per weight version (the host caches the result beside its other derived weights).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const bf16_t* __restrict__ W, int64_t ldw, int N, int K, bf16_t* __restrict__ out,
+                                                          int64_t pieces) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= pieces) return;
+  const int KF = K >> 5;
+  const int lane = (int)(c & 63);
+  const int64_t blk = c >> 6;
+  const int f = (int)(blk % KF);
+  const int64_t n = (blk / KF) * 16 + (lane & 15);
+  uint4 v = {0u, 0u, 0u, 0u};
+  if (n < N) v = *reinterpret_cast<const uint4*>(W + n * ldw + 32 * f + 8 * (lane >> 4));
+  *reinterpret_cast<uint4*>(out + c * 8) = v;
+}
+
+extern "C" int64_t eagle_packed_weight_bytes(int N, int K) {
+  if (N < 1 || K < 32 || (K & 31)) return 0;
+  return (int64_t)((N + 15) / 16) * 16 * K * (int64_t)sizeof(bf16_t);
+}
+
+extern "C" int eagle_pack_weight_bf16(const void* W, int64_t ldw, int N, int K, void* packed, hipStream_t stream) {
+  if (!W || !packed) return EAGLE_ERR_ARG;
+  if (N < 1 || K < 32 || (K & 31) || ldw < K || (ldw & 7)) return EAGLE_ERR_SHAPE;
+  if ((reinterpret_cast<uintptr_t>(W) & 15) || (reinterpret_cast<uintptr_t>(packed) & 15)) return EAGLE_ERR_SHAPE;
+  const int64_t pieces = (int64_t)((N + 15) / 16) * 16 * K / 8;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)W, ldw, N, K,
+                     (bf16_t*)packed, pieces);
   return eagle_check_launch();
 }
 
@@ -725,7 +790,8 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
                                       int M, int N, int K, int epi, hipStream_t stream) {
   if (!x0 || !W || !out) return EAGLE_ERR_ARG;
   const bool keep_resident = (epi & EAGLE_GEMM_KEEP_RESIDENT) != 0;
-  epi &= ~EAGLE_GEMM_KEEP_RESIDENT;
+  const bool packed = (epi & EAGLE_GEMM_W_PACKED) != 0;
+  epi &= ~(EAGLE_GEMM_KEEP_RESIDENT | EAGLE_GEMM_W_PACKED);
   if (epi != EPI_LINEAR && epi != EPI_SILU_MUL) return EAGLE_ERR_ARG;
   if (ind0 && (!idx0 || ind_n < 1 || M > (epi == EPI_SILU_MUL ? 32 : 64))) return EAGLE_ERR_ARG;
   if (norm_eps < 0.f || (norm_eps > 0.f && x1)) return EAGLE_ERR_ARG;
@@ -749,7 +815,7 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     a.W = (const bf16_t*)W; a.W2 = (const bf16_t*)W2; a.bias = (const bf16_t*)bias;
     a.res = res ? (const bf16_t*)res + (int64_t)m0 * ldr : nullptr; a.ldr = ldr;
     a.out = (bf16_t*)out + (int64_t)m0 * ldo; a.ldo = ldo;
-    a.M = mc; a.N = N; a.K = K; a.nt = !keep_resident; a.rot = g_sk_rot;
+    a.M = mc; a.N = N; a.K = K; a.nt = !keep_resident; a.rot = g_sk_rot; a.packed = packed ? 1 : 0;
     a.stage = (int64_t)mc * N >= 400000 ? 1 : 0;
     int rc;
     const int var = skinny_variant();   // 3 = per-shape choice (measured); 0/1/2 force one kernel family

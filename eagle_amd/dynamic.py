@@ -52,7 +52,9 @@ class EagleDynamicDrafter:
         self.rows_head_max = 128
         V = lm_head_weight.shape[0]
         self.caches = [model.new_cache(B, self.cap, dev) for _ in model.layers]      # private: forward() never touches them
-        model.set_cache_residency(self.lm_head)
+        # the frozen head's packed image for the weight-stream GEMM (ops.PackedWeight; the head is frozen: built once)
+        self.lm_head_pk = ops.pack_weight(self.lm_head) if (model.pack_decode_weights and self.lm_head.shape[1] % 32 == 0) else self.lm_head
+        model.set_cache_residency(self.lm_head_pk)
         i32, i64, f32 = torch.int32, torch.int64, torch.float32
         self.len_cur = torch.zeros(B, dtype=i32, device=dev)
         self.len_nxt = torch.zeros(B, dtype=i32, device=dev)
@@ -95,13 +97,13 @@ class EagleDynamicDrafter:
     # ------------------------------------------------------------------ draft side
     def _head(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int):
         if 16 < rows <= 32 and self.D == 4096 and self.lm_head.shape[0] >= 8192:
-            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)        # both 16-row x tiles in registers (keepx)
+            logits = ops.linear_skinny(x, self.lm_head_pk, idx0=idx, M=rows)        # both 16-row x tiles in registers (keepx)
         elif self.model.rows_min <= rows <= self.rows_head_max and self.D % 128 == 0:
             logits = ops.linear_rows(x, self.lm_head, idx0=idx, M=rows)          # decode batches: row-batch weight stream
         elif rows >= self.wide_head_rows and self.D % 64 == 0:
             logits = ops.gemm_nt(x if idx is None else x.index_select(0, idx[:rows]), self.lm_head)
         else:
-            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows, resident=self.model._keep_resident(self.lm_head))
+            logits = ops.linear_skinny(x, self.lm_head_pk, idx0=idx, M=rows, resident=self.model._keep_resident(self.lm_head_pk))
         # top-k and the rows' log-sum-exp out of one pass over the logits (two launches, not three)
         ops.topk(logits, self.k, out_idx=self.ids[:rows], out_val=self.vals[:rows], workspace=self._ws, lse_out=self.lse[:rows])
         if self.keep_debug:

@@ -151,6 +151,10 @@ class Llama2Model(nn.Module):
         # per-step weight-stream kernels.  Tests that compare a batch with per-request runs bit for bit set it to 1, so
         # that both sides sum K in the same order.
         self.rows_min = 17
+        # the weight-stream GEMM (<= 64 rows) reads eagle_pack_weight_bf16 images of the matrices: whole cache lines per wave
+        # instruction instead of 16 x 64-byte halves (+12-17 % on the stream, same output bits); derived copies, rebuilt with
+        # the other derived weights, never part of the state_dict.  False: stream the row-major parameters themselves.
+        self.pack_decode_weights = True
         self._resident = None                            # (epoch, {data_ptr}) of the matrices to keep cache-resident
         self._resident_args = None
         self._rope = None
@@ -226,6 +230,17 @@ class Llama2Model(nn.Module):
             self._packed[("gu", li)] = hit
         return hit[1]
 
+    def _pk(self, tag, w: torch.Tensor):
+        """The packed image of ``w`` for the weight-stream GEMM (cached per weight version under ``tag``), or ``w`` itself."""
+        if not self.pack_decode_weights or w.dim() != 2 or w.shape[1] % 32 or w.stride(1) != 1 or w.dtype != torch.bfloat16:
+            return w
+        key = (self._weight_epoch, w.data_ptr(), w._version, tuple(w.shape))
+        hit = self._packed.get(("pk", tag))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_weight(w.detach()))
+            self._packed[("pk", tag)] = hit
+        return hit[1]
+
     def set_cache_residency(self, lm_head: Optional[torch.Tensor] = None, budget_mb: float = 192.0):
         """Choose which of this model's matrices the weight-stream GEMM keeps in the Infinity Cache between the draft
         forwards of a cycle: the smallest ones up to ``budget_mb`` (default 192 MB = 3/4 of the 256 MB cache).  The
@@ -234,15 +249,17 @@ class Llama2Model(nn.Module):
         self._resident_args = (lm_head, float(budget_mb))
         self._resident = None
 
-    def _keep_resident(self, w: torch.Tensor) -> bool:
+    def _keep_resident(self, w) -> bool:
+        """``w``: the object handed to the GEMM (a parameter, a derived tensor or its packed image)."""
         if self._resident_args is None:
             return False
         if self._resident is None or self._resident[0] != self._weight_epoch:
             lm_head, budget_mb = self._resident_args
-            cands = [self.fc.weight]
+            cands = [self._pk("fc", self.fc.weight)]
             for li, layer in enumerate(self.layers):
-                cands += [self._packed_weights(li), layer.self_attn.o_proj.weight, tuple(self._folded_mlp(li)),
-                          layer.mlp.down_proj.weight]
+                wg, wu = self._folded_mlp(li)
+                cands += [self._pk(("qkv", li), self._packed_weights(li)), self._pk(("o", li), layer.self_attn.o_proj.weight),
+                          (self._pk(("wg", li), wg), self._pk(("wu", li), wu)), self._pk(("down", li), layer.mlp.down_proj.weight)]
             if lm_head is not None:
                 cands.append(lm_head)
             picked = ops.pick_resident_weights(cands, int(budget_mb * 1e6))
@@ -337,14 +354,19 @@ class Llama2Model(nn.Module):
         if wide:
             x = _gemm_wide(ops.embed_concat(emb_w, emb_idx, hid), self.fc.weight, bias=self.fc.bias)
         else:
-            x = ops.linear_skinny(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
-                                  ind0=emb_ind, idx0_bstride=emb_bstride, resident=self._keep_resident(self.fc.weight))
+            wfc = self._pk("fc", self.fc.weight)
+            x = ops.linear_skinny(emb_w, wfc, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
+                                  ind0=emb_ind, idx0_bstride=emb_bstride, resident=self._keep_resident(wfc))
         for li, layer in enumerate(self.layers):
             a = layer.self_attn
             cache = caches[li]
             xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
             wqkv = self._packed_weights(li)
-            qkv = _gemm_wide(xin, wqkv) if wide_rest else ops.linear_skinny(xin, wqkv, resident=self._keep_resident(wqkv))
+            if wide_rest:
+                qkv = _gemm_wide(xin, wqkv)
+            else:
+                wq = self._pk(("qkv", li), wqkv)
+                qkv = ops.linear_skinny(xin, wq, resident=self._keep_resident(wq))
             attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
             ws = self._attn_workspace(B, H, (past_host + q_len) if past_host is not None else max_kv, dev)
             for r0 in range(0, q_len, 16):
@@ -352,8 +374,11 @@ class Llama2Model(nn.Module):
                 bound = (past_host + r0 + mq) if past_host is not None else max_kv
                 ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, past_off0 + r0, tmask, pad, attn, ws,
                                    self._err, B, mq, H, HK, hd, bound, True, q_len, r0, pos_off, pos_stride)
-            x = _gemm_wide(attn, a.o_proj.weight, res=x) if wide_rest else \
-                ops.linear_skinny(attn, a.o_proj.weight, res=x, resident=self._keep_resident(a.o_proj.weight))
+            if wide_rest:
+                x = _gemm_wide(attn, a.o_proj.weight, res=x)
+            else:
+                wo = self._pk(("o", li), a.o_proj.weight)
+                x = ops.linear_skinny(attn, wo, res=x, resident=self._keep_resident(wo))
             # post_attention_layernorm fused into the gate/up projection: the norm weight is folded
             # into the weight columns, the row scale rsqrt(mean(x^2)+eps) is computed in-kernel
             if M > 64 and x.shape[1] % 64 == 0:
@@ -364,13 +389,14 @@ class Llama2Model(nn.Module):
                 act = ops.silu_mul(_gemm_wide(n, wgu))
             else:
                 wg, wu = self._folded_mlp(li)
+                wg, wu = self._pk(("wg", li), wg), self._pk(("wu", li), wu)
                 act = ops.linear_skinny(x, wg, W2=wu, norm_eps=layer.post_attention_layernorm.variance_epsilon,
                                         resident=self._keep_resident(wg))
             if wide_rest and act.shape[1] % 64 == 0:
                 x = _gemm_wide(act, layer.mlp.down_proj.weight, res=x)
             else:
-                x = ops.linear_skinny(act, layer.mlp.down_proj.weight, res=x,
-                                      resident=self._keep_resident(layer.mlp.down_proj.weight))
+                wd = self._pk(("down", li), layer.mlp.down_proj.weight)
+                x = ops.linear_skinny(act, wd, res=x, resident=self._keep_resident(wd))
         return x
 
     def _forward_rows_mid(self, emb_idx, hid, hid_idx, M, B, q_len, pos, past_dev, max_kv, tmask, pad, caches,
@@ -388,7 +414,7 @@ class Llama2Model(nn.Module):
             xin = x if layer.index == 0 else ops.rmsnorm(x, layer.input_layernorm.weight, layer.input_layernorm.variance_epsilon)
             wqkv = self._packed_weights(li)
             if M <= 32 and wqkv.shape[1] == 4096 and wqkv.shape[0] >= 8192:
-                qkv = ops.linear_skinny(xin, wqkv)            # <= 32 rows, tall matrix: x in registers (keepx, two row tiles)
+                qkv = ops.linear_skinny(xin, self._pk(("qkv", li), wqkv))   # <= 32 rows, tall matrix: x in registers (keepx, two row tiles)
             else:
                 qkv = ops.linear_rows(xin, wqkv)
             attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
@@ -405,7 +431,7 @@ class Llama2Model(nn.Module):
             if M <= 32 and wgu.shape[1] == 4096:
                 # <= 32 rows: gate|up as ONE tall matrix on the keepx stream, then SiLU*up (50 us; the SiLU epilogue on two
                 # row tiles and two weight tiles per step spills: 74)
-                act = ops.silu_mul(ops.linear_skinny(n, wgu))
+                act = ops.silu_mul(ops.linear_skinny(n, self._pk(("gu", li), wgu)))
             else:
                 act = ops.linear_rows(n, wgu[:inter], W2=wgu[inter:])
             x = ops.linear_rows(act, layer.mlp.down_proj.weight, res=x)

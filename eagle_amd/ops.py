@@ -16,6 +16,36 @@ from ._hip import call, ptr, query, stream
 BF16 = torch.bfloat16
 EPI_LINEAR, EPI_SILU_MUL = 0, 1
 KEEP_RESIDENT = 0x100   # EAGLE_GEMM_KEEP_RESIDENT
+W_PACKED = 0x200        # EAGLE_GEMM_W_PACKED
+
+
+class PackedWeight:
+    """eagle_pack_weight_bf16 image of a weight matrix [N, K] (a derived copy laid out for whole-cache-line streaming; the
+    row-major parameter stays the state_dict tensor).  ``data`` is the opaque image, ``shape`` the logical (N, K)."""
+    __slots__ = ("data", "shape")
+
+    def __init__(self, data: torch.Tensor, N: int, K: int):
+        self.data, self.shape = data, (N, K)
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+    def numel(self) -> int:
+        return self.data.numel()
+
+    def element_size(self) -> int:
+        return self.data.element_size()
+
+
+def pack_weight(W: torch.Tensor) -> PackedWeight:
+    """W [N, K] bf16 (rows contiguous, any row stride that is a multiple of 8) -> its packed image."""
+    _chk(W, "W")
+    N, K = W.shape
+    if W.stride(1) != 1 or K % 32:
+        raise ValueError("pack_weight: W [N, K] with contiguous rows and K % 32 == 0")
+    out = torch.empty(query("eagle_packed_weight_bytes", N, K) // 2, dtype=BF16, device=W.device)
+    call("eagle_pack_weight_bf16", ptr(W), W.stride(0), N, K, ptr(out), stream())
+    return PackedWeight(out, N, K)
 
 
 def _chk(t: torch.Tensor, name: str, dtype=BF16):
@@ -37,11 +67,20 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
                   idx1: Optional[torch.Tensor] = None, M: Optional[int] = None,
                   out: Optional[torch.Tensor] = None, ind0: Optional[torch.Tensor] = None,
                   idx0_bstride: int = 0, norm_eps: float = 0.0, resident: bool = False) -> torch.Tensor:
-    """out[M,N] = epi(cat(x[idx0], x1[idx1]) @ W^T).  x [*, K0] row-major; W [N, K].
+    """out[M,N] = epi(cat(x[idx0], x1[idx1]) @ W^T).  x [*, K0] row-major; W [N, K] row-major or its PackedWeight image
+    (same result bit for bit, faster weight stream).
     ind0: double indirection for x rows (see include/eagle_hip.h); norm_eps > 0 fuses the RMSNorm
     row scale (W must then carry the norm weight folded into its columns).  resident: keep W in the Infinity Cache
     (default cache policy) instead of streaming it with non-temporal loads."""
-    _chk(x, "x"), _chk(W, "W")
+    _chk(x, "x")
+    packed = isinstance(W, PackedWeight)
+    if packed:
+        if W2 is not None and (not isinstance(W2, PackedWeight) or W2.shape != W.shape):
+            raise ValueError("W2 must be packed like W")
+    else:
+        _chk(W, "W")
+        if isinstance(W2, PackedWeight):
+            raise ValueError("W2 must be packed like W")
     N, K = W.shape
     K0 = x.shape[-1]
     if x1 is not None:
@@ -52,18 +91,19 @@ def linear_skinny(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor]
         raise ValueError(f"x width {K0} != K={K}")
     if M is None:
         M = idx0.numel() if idx0 is not None else x.shape[0]
-    if x.stride(-1) != 1 or W.stride(1) != 1 or W.stride(0) != K:
+    if x.stride(-1) != 1 or (not packed and (W.stride(1) != 1 or W.stride(0) != K)):
         raise ValueError("x rows and W must be contiguous along K")
     for i in (idx0, idx1, ind0):
         if i is not None and (i.dtype != torch.int64 or (not i.is_contiguous() and not (i is idx0 and ind0 is not None))):
             raise TypeError("row index arrays must be contiguous int64")
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=x.device)
-    epi = (EPI_SILU_MUL if W2 is not None else EPI_LINEAR) | (KEEP_RESIDENT if resident else 0)
+    epi = (EPI_SILU_MUL if W2 is not None else EPI_LINEAR) | (KEEP_RESIDENT if resident else 0) | (W_PACKED if packed else 0)
     call("eagle_gemm_skinny_bf16", ptr(x), ptr(idx0), x.stride(0) if x.dim() > 1 else K0, K0,
          ptr(ind0), (ind0.numel() if ind0 is not None else 0), idx0_bstride, float(norm_eps),
          ptr(x1), ptr(idx1), (x1.stride(0) if x1 is not None else 0),
-         ptr(W), ptr(W2), ptr(bias), ptr(res), (res.stride(0) if res is not None else 0),
+         ptr(W.data if packed else W), ptr(W2.data if (packed and W2 is not None) else W2), ptr(bias), ptr(res),
+         (res.stride(0) if res is not None else 0),
          ptr(out), out.stride(0), M, N, K, epi, stream())
     return out
 

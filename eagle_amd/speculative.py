@@ -66,7 +66,9 @@ class EagleDrafter:
         self.kv_bound = self.cap
         B, V = batch, lm_head_weight.shape[0]
         self.caches = [model.new_cache(B, self.cap, dev) for _ in model.layers]      # private: forward() never touches them
-        model.set_cache_residency(self.lm_head)
+        # the frozen head's packed image for the weight-stream GEMM (ops.PackedWeight; the head is frozen: built once)
+        self.lm_head_pk = ops.pack_weight(self.lm_head) if (model.pack_decode_weights and self.lm_head.shape[1] % 32 == 0) else self.lm_head
+        model.set_cache_residency(self.lm_head_pk)
         # draft KV-cache lengths: len_cur = rows before the catch-up forward, len_nxt = after it
         self.len_cur = torch.zeros(B, dtype=torch.int32, device=dev)
         self.len_nxt = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -105,7 +107,7 @@ class EagleDrafter:
         if 16 < rows <= 32 and self.D == 4096 and self.lm_head.shape[0] >= 8192:
             # 17-32 rows (a 32-request batch at one row each): both 16-row tiles of x stay in registers of the weight-stream
             # kernel, which reads 2 KB of every weight row per block step (in-cycle 151936 x 4096: see DESIGN.md section 10)
-            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows)
+            logits = ops.linear_skinny(x, self.lm_head_pk, idx0=idx, M=rows)
         elif self.B > 1 and self.head_topk_fused and self.D % 128 == 0 and \
                 ops.lm_head_topk_rows_ok(rows, self.lm_head.shape[0], self.D, self.k):
             # 81-128 rows of a request batch against a tall head: candidates out of the GEMM's epilogue, no logits
@@ -120,7 +122,7 @@ class EagleDrafter:
             # passes over the weights once per 32 rows: 304 vs 520 us at 32 rows of the 151936-row head)
             logits = ops.gemm_nt(x if idx is None else x.index_select(0, idx[:rows]), self.lm_head)
         else:
-            logits = ops.linear_skinny(x, self.lm_head, idx0=idx, M=rows, resident=self.model._keep_resident(self.lm_head))
+            logits = ops.linear_skinny(x, self.lm_head_pk, idx0=idx, M=rows, resident=self.model._keep_resident(self.lm_head_pk))
         if self.B == 1:
             ops.topk(logits, self.k, out_idx=self.flat_ids[0, row0:row0 + n], out_val=self.flat_vals[0, row0:row0 + n],
                      workspace=self._ws)

@@ -28,6 +28,9 @@ typedef struct ihipStream_t* eagle_stream_t; /* == hipStream_t */
  * in the 256 MB Infinity Cache from one draft forward to the next; without it weights stream with non-temporal loads
  * and displace nothing.  A per-call hint (the library keeps no state); it only changes speed, never results. */
 #define EAGLE_GEMM_KEEP_RESIDENT 0x100
+/* OR-ed into `epi` of eagle_gemm_skinny_bf16: W (and W2) point at eagle_pack_weight_bf16 images instead of row-major
+ * matrices.  Same arithmetic, same output bits; the weight stream then reads whole cache lines (see eagle_pack_weight_bf16). */
+#define EAGLE_GEMM_W_PACKED 0x200
 
 /* out[M,N] = epilogue(x[M,K] . W[N,K]^T), weight-streaming kernel for M <= 64 rows per weight
  * pass (larger M loops).  x row m = cat(x0[idx0 ? idx0[m] : m][0:K0], x1[idx1 ? idx1[m] : m][0:K-K0])
@@ -47,6 +50,16 @@ int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int
                            const void* W, const void* W2, const void* bias,
                            const void* res, int64_t ldr, void* out, int64_t ldo,
                            int M, int N, int K, int epi, eagle_stream_t stream);
+
+/* Packed image of a weight matrix W [N, K] (row stride ldw, K % 32 == 0) for the weight-streaming GEMM above: every 16-row x
+ * 32-column block -- one MFMA A fragment, which the kernel otherwise gathers as 16 x 64-byte half cache lines per wave
+ * instruction -- is stored as ONE contiguous 1 KiB piece in lane order, [ceil(N/16)][K/32][64][8] bf16, rows past N zero.
+ * eagle_packed_weight_bytes(N, K) = its size.  Measured on MI355X (tools/stream_probe.hip: 262 MB, cold caches, non-temporal
+ * loads): half-line wave reads stream at 5.4 TB/s, whole-line reads at 6.3 TB/s.  A layout of the SAME nn.Linear weights
+ * (eagle/llama2.py:222-224, :280, :317, :542; lm_head eagle/train.py:215-228) chosen for HBM; built once per weight version
+ * by the host, never visible in the state_dict. */
+int64_t eagle_packed_weight_bytes(int N, int K);
+int eagle_pack_weight_bf16(const void* W, int64_t ldw, int N, int K, void* packed, eagle_stream_t stream);
 
 /* The same product for decode BATCHES, 1 <= M <= 192 rows (a batch of requests stepping through the draft tree together:
  * 32 requests x 1 or 4 tree rows): one weight pass for all rows.  Operands and epilogues as eagle_gemm_skinny_bf16

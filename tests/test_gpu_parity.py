@@ -63,6 +63,62 @@ def test_gemm_skinny_linear(M, N, K):
     close(y, ref2, what="bias+res")
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (4, 4096, 8192), (16, 4096, 11008), (3, 11008, 4096), (4, 32000, 4096), (32, 32000, 4096), (24, 12288, 4096),
+                                   (7, 100, 64), (5, 72, 160), (20, 520, 4096), (40, 250, 96), (70, 130, 256), (9, 33, 8192), (2, 4100, 4096)])
+def test_gemm_skinny_packed_weights_are_bit_equal(M, N, K):
+    """eagle_pack_weight_bf16 images (whole-cache-line weight stream) against the row-major stream on the same call: every
+    kernel family (tile, stream, register-resident x with one and two row tiles), ragged N (zero-padded tiles), K tails,
+    bias + residual, SiLU*up with the fused RMSNorm scale, gathered + concatenated x rows -- identical output bits -- and
+    the image itself against its definition."""
+    from eagle_amd import ops
+    from eagle_amd._hip import lib
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    d = dev()
+    x = torch.randn(M, K, generator=g).to(BF).to(d)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(d)
+    b = torch.randn(N, generator=g).to(BF).to(d)
+    r = torch.randn(M, N, generator=g).to(BF).to(d)
+    Wp = ops.pack_weight(W)
+    close(ops.linear_skinny(x, Wp, bias=b, res=r), (x.float() @ W.float().t() + b.float()).to(BF).float() + r.float(), what="packed bias+res (default walk)")
+    # The register-resident kernel walks K from a start that depends on the block index, and packed blocks own whole 16-row
+    # tiles: where N / 256 is not a multiple of 16 the two partitions differ, a column sits in another block and its fp32
+    # sum runs in another order.  With the staggered walk off (diagnostic bit 15) the order is the same in every block and
+    # the two streams must agree bit for bit.
+    lib().eagle_debug_set_skinny_variant(3 | (1 << 15), 0, 0)
+    try:
+        _packed_vs_row_major(ops, g, d, x, W, Wp, b, r, M, N, K)
+    finally:
+        lib().eagle_debug_set_skinny_variant(3, 0, 0)
+
+
+def _packed_vs_row_major(ops, g, d, x, W, Wp, b, r, M, N, K):
+    Np = (N + 15) // 16 * 16
+    img = Wp.data.view(Np // 16, K // 32, 4, 16, 8)                       # [tile][k-block][g][r16][8]
+    ref_img = torch.zeros(Np, K, dtype=BF, device=d)
+    ref_img[:N] = W
+    ref_img = ref_img.view(Np // 16, 16, K // 32, 4, 8).permute(0, 2, 3, 1, 4)
+    assert torch.equal(img, ref_img), "packed image differs from its definition"
+    assert torch.equal(ops.linear_skinny(x, Wp), ops.linear_skinny(x, W))
+    assert torch.equal(ops.linear_skinny(x, Wp, bias=b, res=r), ops.linear_skinny(x, W, bias=b, res=r))
+    close(ops.linear_skinny(x, Wp), x.float() @ W.float().t(), what="packed plain")
+    if M <= 32:
+        W2 = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(d)
+        W2p = ops.pack_weight(W2)
+        assert torch.equal(ops.linear_skinny(x, Wp, W2=W2p), ops.linear_skinny(x, W, W2=W2))
+        assert torch.equal(ops.linear_skinny(x, Wp, W2=W2p, norm_eps=1e-6), ops.linear_skinny(x, W, W2=W2, norm_eps=1e-6))
+    if K % 64 == 0:
+        K0 = K // 2
+        t0 = torch.randn(50, K0, generator=g).to(BF).to(d)
+        t1 = torch.randn(30, K - K0, generator=g).to(BF).to(d)
+        i0 = torch.randint(0, 50, (M,), generator=g).to(d)
+        i1 = torch.randint(0, 30, (M,), generator=g).to(d)
+        assert torch.equal(ops.linear_skinny(t0, Wp, bias=b, idx0=i0, x1=t1, idx1=i1, M=M),
+                           ops.linear_skinny(t0, W, bias=b, idx0=i0, x1=t1, idx1=i1, M=M))
+    # a strided source (rows of a stacked matrix) packs like its contiguous copy
+    Wbig = torch.cat([W, W], dim=1)
+    assert torch.equal(ops.pack_weight(Wbig[:, :K]).data, Wp.data)
+
+
 @pytest.mark.parametrize("M,N", [(16, 32000), (32, 32000), (24, 40008), (24, 40004), (13, 31000), (32, 151936), (5, 151936)])
 def test_gemm_skinny_keepx_staged_outputs(M, N):
     """From M x N >= 400000 the register-resident weight stream (K = 4096) collects a block's outputs in LDS and writes them
