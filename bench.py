@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--train-ga", type=int, default=2, help="gradient accumulation steps (pages/train_qwen_3.md:20)")
     ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--resident-mb", type=float, default=None, help="Infinity-Cache residency budget of the draft head's matrices (default: the drafter's)")
     ap.add_argument("--plant", type=float, default=0.8, help="probability that the synthetic verifier agrees with a drafted child")
     return ap.parse_args()
 
@@ -585,6 +586,8 @@ def main():
     note(f"world {world}, backend {backend if world > 1 else 'none'}: building the draft head")
     cfg, model, lm_head = make_model(a.config, dev, seed=0)
     drafter = EagleDrafter(model, lm_head, expand=a.expand, batch=1, max_ctx=2048)
+    if a.resident_mb is not None:
+        model.set_cache_residency(drafter.lm_head_pk, a.resident_mb)
     n_fw = 1 + len(drafter.tb.steps)
     # the host knows an upper bound of the context for the whole run: tighter attention grids
     drafter.kv_bound = min(drafter.cap, (a.ctx + (a.warmup + a.steps + 1) * drafter.W + drafter.n_fwd + 63) // 64 * 64)

@@ -31,6 +31,7 @@
 #define GR_EPI_LINEAR 0
 #define GR_EPI_SILU_MUL 1
 #define GR_KEEP_RESIDENT 0x100          // accepted and ignored: this path always streams W non-temporally
+#define GR_W_PACKED 0x200               // W / W2 are eagle_pack_weight_bf16 images (gemm_skinny.hip): whole-line weight reads
 
 typedef __attribute__((ext_vector_type(4))) unsigned int gr_u32x4;
 
@@ -49,7 +50,13 @@ struct RowsArgs {
   int rotate;              // K-walk stagger between neighbouring column tiles, in super-steps (0: none)
   unsigned long long* cand; int topk;   // gemm_rows_wide_kernel<MT, true>: [M][tiles][topk] candidate records instead of `out`
   int tile_cols;           // gemm_rows_stream_kernel: output columns per column tile: BN, or 3/4 BN with the fourth consumer wave idle
+  int packed;              // host-side only: selects the instantiations that read packed weight images
 };
+
+// lane's 16-byte piece of 16-row tile T, k-block k / 32 in a packed image (gemm_skinny.hip: [N/16][K/32][64 lanes][8])
+__device__ __forceinline__ const bf16_t* gr_pk(const bf16_t* base, int T, int K, int64_t k, int lane) {
+  return base + ((int64_t)T * (K >> 5) + (k >> 5)) * 512 + lane * 8;
+}
 
 template <int RT, int EPI> struct RowsGeom {
   static constexpr int RTW = (EPI == GR_EPI_SILU_MUL) ? RT / 2 : RT;   // 16-column output tiles per wave
@@ -97,7 +104,7 @@ __device__ __forceinline__ void rows_epilogue(const RowsArgs& p, int tile, int w
 
 // MT 16-row activation tiles (M <= 16*MT), RT 16-row weight tiles per consumer wave, S weight register stages,
 // XS activation LDS buffers of MT*16 rows x 128 k.
-template <int MT, int RT, int EPI, int S, int XS, int NL>
+template <int MT, int RT, int EPI, int S, int XS, int NL, bool PK = false>
 __global__ __launch_bounds__((GR_NW + NL) * 64) void gemm_rows_stream_kernel(RowsArgs p) {
   using G = RowsGeom<RT, EPI>;
   constexpr int XBYTES = MT * 16 * 256;                  // one x chunk: MT*16 rows of 128 bf16
@@ -172,11 +179,14 @@ __global__ __launch_bounds__((GR_NW + NL) * 64) void gemm_rows_stream_kernel(Row
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
     const int u = (EPI == GR_EPI_SILU_MUL) ? (t >> 1) : t;
-    int n = tile * p.tile_cols + (wave * G::RTW + u) * 16 + r16;
+    const int nb = tile * p.tile_cols + (wave * G::RTW + u) * 16;      // a multiple of 16: one packed tile
+    int n = nb + r16;
     n = n < p.N ? n : p.N - 1;                           // clamped rows compute values that are never stored
     const bf16_t* base = (EPI == GR_EPI_SILU_MUL && (t & 1)) ? p.W2 : p.W;
-    wp[t] = base + (int64_t)n * p.ldw + 8 * g + ((int64_t)j_beg << 7);
+    wp[t] = PK ? gr_pk(base, min(nb >> 4, (p.N - 1) >> 4), p.K, (int64_t)j_beg << 7, lane)
+               : base + (int64_t)n * p.ldw + 8 * g + ((int64_t)j_beg << 7);
   }
+  constexpr int KS = PK ? 16 : 1, SS = PK ? 512 : 32;     // element steps per k and per 32-k sub-step (packed: 1 KiB blocks)
   // Every stage refill is issued unconditionally (past the slice's last super-step it reads one hot line of W, the
   // same address in every lane) and the main loop body is branch-free: hipcc's counted vmcnt waits are exact only
   // when the number of loads between a stage's issue and its use is the same on every path.
@@ -187,7 +197,7 @@ __global__ __launch_bounds__((GR_NW + NL) * 64) void gemm_rows_stream_kernel(Row
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int t = 0; t < RT; ++t) {
-        const bf16_t* src = live ? wp[t] + (kstep(j) << 7) + s * 32 : p.W;
+        const bf16_t* src = live ? wp[t] + (kstep(j) << 7) * KS + s * SS : p.W;
         st[s][t] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(src));
       }
   };
@@ -346,7 +356,7 @@ template <int N> struct gw_int { static constexpr int value = N; };
 // columns l, l+16, ...: keys = value << 16 | 0xffff - column, the lowest column wins a tie) and writes them as candidate
 // records [row][tile][topk] in topk.hip's format -- eagle_topk_merge_candidates finishes the job.  Against logits + the
 // two-launch top-k this saves the 39 MB store burst of a 128 x 151936 tile row and the 39 MB pass of stage 1.
-template <int MT, bool TOPK = false>
+template <int MT, bool TOPK = false, bool PK = false>
 __global__ __launch_bounds__(GW_NW * 64) void gemm_rows_wide_kernel(RowsArgs p) {
   constexpr int S = 2, XS = S + 1;
   constexpr int XBYTES = MT * 16 * 256;
@@ -399,21 +409,28 @@ __global__ __launch_bounds__(GW_NW * 64) void gemm_rows_wide_kernel(RowsArgs p) 
     for (int t = 0; t < RT; ++t) {
       int n = (gb + wg0 + t) * 16 + r16;
       n = n < p.N ? n : p.N - 1;                           // the last group of the last tile: clamped rows are never stored
-      wp[t] = p.W + (int64_t)n * p.ldw + 8 * g;
+      wp[t] = PK ? gr_pk(p.W, min(gb + wg0 + t, (p.N - 1) >> 4), p.K, 0, lane) : p.W + (int64_t)n * p.ldw + 8 * g;
     }
     bf16x8 a[S][4][RT];
     auto issue_w = [&](bf16x8 (&st)[4][RT], int j) {       // past the last super-step: one hot line (two stages per wave)
       const bool live = j < nj;
-      const int k = live ? kstep(j) << 7 : 0;
+      const int k = live ? (kstep(j) << 7) * (PK ? 16 : 1) : 0;   // packed: a 32-k block is 512 elements on
 #pragma unroll
       for (int s = 0; s < 4; ++s)                          // s-major: the order the counted waits rely on
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
           const bf16_t* src = live ? wp[t] + k : p.W;
-          if (s == 0) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(st[s][t]) : "v"(src) : "memory");
-          if (s == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:64 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
-          if (s == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:128 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
-          if (s == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:192 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+          if (PK) {                                        // the next k-block of the same tile: the next 1 KiB
+            if (s == 0) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+            if (s == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:1024 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+            if (s == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:2048 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+            if (s == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:3072 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+          } else {
+            if (s == 0) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+            if (s == 1) asm volatile("global_load_dwordx4 %0, %1, off offset:64 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+            if (s == 2) asm volatile("global_load_dwordx4 %0, %1, off offset:128 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+            if (s == 3) asm volatile("global_load_dwordx4 %0, %1, off offset:192 nt" : "=v"(st[s][t]) : "v"(src) : "memory");
+          }
         }
     };
     f32x4 acc[MT][RT];
@@ -621,7 +638,7 @@ static RowsPlan gr_plan(int M, int N, int K, int epi, bool has_x1 = false) {
 }
 
 extern "C" int64_t eagle_gemm_rows_workspace_bytes(int M, int N, int K, int epi) {
-  epi &= ~GR_KEEP_RESIDENT;
+  epi &= ~(GR_KEEP_RESIDENT | GR_W_PACKED);
   if (M < 1 || M > GR_MAX_ROWS || N < 1 || K < 128 || (K & 127) || (epi != GR_EPI_LINEAR && epi != GR_EPI_SILU_MUL)) return 0;
   const RowsPlan pl = gr_plan(M, N, K, epi);
   if (pl.ks == 1) return 0;
@@ -634,7 +651,8 @@ static int gr_launch_s(const RowsArgs& a, hipStream_t st) {
   // (3 x 48 KB of the 160 KB)
   constexpr int XS = MT > 8 ? 3 : 4;
   constexpr int NL = MT <= 2 ? 1 : MT <= 4 ? 2 : 4;
-  hipLaunchKernelGGL((gemm_rows_stream_kernel<MT, 2, EPI, S, XS, NL>), dim3(a.tiles * a.ks), dim3((GR_NW + NL) * 64), 0, st, a);
+  if (a.packed) hipLaunchKernelGGL((gemm_rows_stream_kernel<MT, 2, EPI, S, XS, NL, true>), dim3(a.tiles * a.ks), dim3((GR_NW + NL) * 64), 0, st, a);
+  else hipLaunchKernelGGL((gemm_rows_stream_kernel<MT, 2, EPI, S, XS, NL, false>), dim3(a.tiles * a.ks), dim3((GR_NW + NL) * 64), 0, st, a);
   int rc = eagle_check_launch();
   if (rc || a.ks == 1 || a.counters) return rc;
   hipLaunchKernelGGL((gemm_rows_reduce_kernel<MT, 2, EPI>), dim3(a.tiles, (a.M + 15) / 16), dim3(GR_NW * 64), 0, st, a);
@@ -652,8 +670,13 @@ static int gr_launch(const RowsArgs& a, hipStream_t st) {
 template <int EPI>
 static int gr_launch_mt(const RowsArgs& a, int mt, hipStream_t st, int wide) {
   if (wide) {
-    if (mt == 6) hipLaunchKernelGGL((gemm_rows_wide_kernel<6>), dim3(a.tiles), dim3(GW_NW * 64), 0, st, a);
-    else hipLaunchKernelGGL((gemm_rows_wide_kernel<8>), dim3(a.tiles), dim3(GW_NW * 64), 0, st, a);
+    if (a.packed) {
+      if (mt == 6) hipLaunchKernelGGL((gemm_rows_wide_kernel<6, false, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, st, a);
+      else hipLaunchKernelGGL((gemm_rows_wide_kernel<8, false, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, st, a);
+    } else {
+      if (mt == 6) hipLaunchKernelGGL((gemm_rows_wide_kernel<6>), dim3(a.tiles), dim3(GW_NW * 64), 0, st, a);
+      else hipLaunchKernelGGL((gemm_rows_wide_kernel<8>), dim3(a.tiles), dim3(GW_NW * 64), 0, st, a);
+    }
     return eagle_check_launch();
   }
   switch (mt) {
@@ -675,7 +698,9 @@ extern "C" int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t
                                     const void* res, int64_t ldr, void* out, int64_t ldo,
                                     int M, int N, int K, int epi, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   if (!x0 || !W || !out) return EAGLE_ERR_ARG;
-  epi &= ~GR_KEEP_RESIDENT;
+  const bool packed = (epi & GR_W_PACKED) != 0;
+  epi &= ~(GR_KEEP_RESIDENT | GR_W_PACKED);
+  if (packed) ldw = K;                                   // a packed image has no row stride
   if (epi != GR_EPI_LINEAR && epi != GR_EPI_SILU_MUL) return EAGLE_ERR_ARG;
   if (ind0 && (!idx0 || ind_n < 1)) return EAGLE_ERR_ARG;
   if (epi == GR_EPI_SILU_MUL && (!W2 || bias || res)) return EAGLE_ERR_ARG;
@@ -698,7 +723,7 @@ extern "C" int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t
   a.M = M; a.N = N; a.K = K;
   a.rotate = pl.wide ? 2 * g_rows_rotate : g_rows_rotate;   // wide tiles: every second 256-byte column (measured: 300 vs 337 us)
   a.tiles = pl.tiles; a.ks = pl.ks; a.kchunk = pl.kchunk; a.tile_cols = pl.tile_cols;
-  a.cand = nullptr; a.topk = 0;
+  a.cand = nullptr; a.topk = 0; a.packed = packed ? 1 : 0;
   a.slab = workspace ? (float*)((char*)workspace + GR_COUNTER_BYTES) : nullptr;
   a.counters = (pl.ks > 1 && !g_rows_two_launch) ? (int*)workspace : nullptr;
   return epi == GR_EPI_SILU_MUL ? gr_launch_mt<GR_EPI_SILU_MUL>(a, pl.mt, stream, 0) : gr_launch_mt<GR_EPI_LINEAR>(a, pl.mt, stream, pl.wide);
@@ -731,6 +756,8 @@ extern "C" int eagle_lm_head_topk_rows_bf16(const void* x0, const int64_t* idx0,
   if (ind0 && (!idx0 || ind_n < 1)) return EAGLE_ERR_ARG;
   RowsPlan pl;
   if (!gr_topk_plan(M, N, K, k, pl)) return EAGLE_ERR_SHAPE;
+  const bool packed = ldw == 0;                          // ldw == 0: W is an eagle_pack_weight_bf16 image
+  if (packed) ldw = K;
   if ((ld0 & 7) || (ldw & 7) || ldw < K || !gr_al16(x0) || !gr_al16(W) || (reinterpret_cast<uintptr_t>(workspace) & 7)) return EAGLE_ERR_SHAPE;
   if (ld0 < K && !idx0 && M > 1) return EAGLE_ERR_SHAPE;
   if (workspace_bytes < (int64_t)pl.mt * 16 * pl.tiles * k * 8) return EAGLE_ERR_ARG;
@@ -745,8 +772,11 @@ extern "C" int eagle_lm_head_topk_rows_bf16(const void* x0, const int64_t* idx0,
   a.rotate = 2 * g_rows_rotate;
   a.tiles = pl.tiles; a.ks = 1; a.kchunk = K >> 7; a.tile_cols = 0;
   a.slab = nullptr; a.counters = nullptr;
-  a.cand = (unsigned long long*)workspace; a.topk = k;
-  if (pl.mt == 6) hipLaunchKernelGGL((gemm_rows_wide_kernel<6, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, stream, a);
+  a.cand = (unsigned long long*)workspace; a.topk = k; a.packed = packed ? 1 : 0;
+  if (packed) {
+    if (pl.mt == 6) hipLaunchKernelGGL((gemm_rows_wide_kernel<6, true, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, stream, a);
+    else hipLaunchKernelGGL((gemm_rows_wide_kernel<8, true, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, stream, a);
+  } else if (pl.mt == 6) hipLaunchKernelGGL((gemm_rows_wide_kernel<6, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, stream, a);
   else hipLaunchKernelGGL((gemm_rows_wide_kernel<8, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, stream, a);
   int rc = eagle_check_launch();
   if (rc) return rc;

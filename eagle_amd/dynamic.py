@@ -99,7 +99,7 @@ class EagleDynamicDrafter:
         if 16 < rows <= 32 and self.D == 4096 and self.lm_head.shape[0] >= 8192:
             logits = ops.linear_skinny(x, self.lm_head_pk, idx0=idx, M=rows)        # both 16-row x tiles in registers (keepx)
         elif self.model.rows_min <= rows <= self.rows_head_max and self.D % 128 == 0:
-            logits = ops.linear_rows(x, self.lm_head, idx0=idx, M=rows)          # decode batches: row-batch weight stream
+            logits = ops.linear_rows(x, self.lm_head_pk, idx0=idx, M=rows)          # decode batches: row-batch weight stream
         elif rows >= self.wide_head_rows and self.D % 64 == 0:
             logits = ops.gemm_nt(x if idx is None else x.index_select(0, idx[:rows]), self.lm_head)
         else:

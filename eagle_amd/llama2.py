@@ -406,7 +406,7 @@ class Llama2Model(nn.Module):
         dev = hid.device
         H, HK, hd = self._dims()
         emb_w = self.embed_tokens.weight
-        x = ops.linear_rows(emb_w, self.fc.weight, bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
+        x = ops.linear_rows(emb_w, self._pk("fc", self.fc.weight), bias=self.fc.bias, idx0=emb_idx, x1=hid, idx1=hid_idx, M=M,
                             ind0=emb_ind, idx0_bstride=emb_bstride)
         for li, layer in enumerate(self.layers):
             a = layer.self_attn
@@ -416,7 +416,7 @@ class Llama2Model(nn.Module):
             if M <= 32 and wqkv.shape[1] == 4096 and wqkv.shape[0] >= 8192:
                 qkv = ops.linear_skinny(xin, self._pk(("qkv", li), wqkv))   # <= 32 rows, tall matrix: x in registers (keepx, two row tiles)
             else:
-                qkv = ops.linear_rows(xin, wqkv)
+                qkv = ops.linear_rows(xin, self._pk(("qkv", li), wqkv))
             attn = torch.empty((M, H * hd), dtype=torch.bfloat16, device=dev)
             ws = self._attn_workspace(B, H, (past_host + q_len) if past_host is not None else max_kv, dev)
             for r0 in range(0, q_len, 16):
@@ -424,7 +424,7 @@ class Llama2Model(nn.Module):
                 bound = (past_host + r0 + mq) if past_host is not None else max_kv
                 ops.tree_attention(qkv, pos, cos, sin, cache.k, cache.v, past_dev, past_off0 + r0, tmask, pad, attn, ws,
                                    self._err, B, mq, H, HK, hd, bound, True, q_len, r0, pos_off, pos_stride)
-            x = ops.linear_rows(attn, a.o_proj.weight, res=x)
+            x = ops.linear_rows(attn, self._pk(("o", li), a.o_proj.weight), res=x)
             n = ops.rmsnorm(x, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.variance_epsilon)
             wgu = self._stacked_mlp(li)
             inter = wgu.shape[0] // 2
@@ -433,8 +433,8 @@ class Llama2Model(nn.Module):
                 # row tiles and two weight tiles per step spills: 74)
                 act = ops.silu_mul(ops.linear_skinny(n, self._pk(("gu", li), wgu)))
             else:
-                act = ops.linear_rows(n, wgu[:inter], W2=wgu[inter:])
-            x = ops.linear_rows(act, layer.mlp.down_proj.weight, res=x)
+                act = ops.linear_rows(n, self._pk(("g", li), wgu[:inter]), W2=self._pk(("u", li), wgu[inter:]))
+            x = ops.linear_rows(act, self._pk(("down", li), layer.mlp.down_proj.weight), res=x)
         return x
 
     # ------------------------------------------------------------------ forward

@@ -145,7 +145,12 @@ def linear_rows(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] =
     """linear_skinny's product for a decode batch of up to 192 rows in ONE weight pass (eagle_gemm_rows_bf16): W straight
     to registers, x through LDS, K split over workgroups where the matrix has few column tiles.  W (and W2) [N, K] with
     any row stride that is a multiple of 8; K (and the cat boundary) multiples of 128."""
-    _chk(x, "x"), _chk(W, "W")
+    _chk(x, "x")
+    packed = isinstance(W, PackedWeight)
+    if not packed:
+        _chk(W, "W")
+    if (W2 is not None) and isinstance(W2, PackedWeight) != packed:
+        raise ValueError("W2 must be packed like W")
     N, K = W.shape
     K0 = x.shape[-1]
     if x1 is not None:
@@ -156,20 +161,24 @@ def linear_rows(x: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] =
         raise ValueError(f"x width {K0} != K={K}")
     if M is None:
         M = idx0.numel() if idx0 is not None else x.shape[0]
-    if x.stride(-1) != 1 or W.stride(1) != 1 or (W2 is not None and (W2.stride(1) != 1 or W2.stride(0) != W.stride(0) or W2.shape != W.shape)):
+    if packed:
+        if x.stride(-1) != 1 or (W2 is not None and W2.shape != W.shape):
+            raise ValueError("x rows must be contiguous along K; W2 shaped as W")
+    elif x.stride(-1) != 1 or W.stride(1) != 1 or (W2 is not None and (W2.stride(1) != 1 or W2.stride(0) != W.stride(0) or W2.shape != W.shape)):
         raise ValueError("x rows, W and W2 must be contiguous along K; W2 shaped and strided as W")
     for i in (idx0, idx1, ind0):
         if i is not None and (i.dtype != torch.int64 or (not i.is_contiguous() and not (i is idx0 and ind0 is not None))):
             raise TypeError("row index arrays must be contiguous int64")
     if out is None:
         out = torch.empty((M, N), dtype=BF16, device=x.device)
-    epi = EPI_SILU_MUL if W2 is not None else EPI_LINEAR
+    epi = (EPI_SILU_MUL if W2 is not None else EPI_LINEAR) | (W_PACKED if packed else 0)
     nbytes = query("eagle_gemm_rows_workspace_bytes", M, N, K, epi)
     ws = _rows_workspace(nbytes, x.device) if nbytes else None
     call("eagle_gemm_rows_bf16", ptr(x), ptr(idx0), x.stride(0) if x.dim() > 1 else K0, K0,
          ptr(ind0), (ind0.numel() if ind0 is not None else 0), idx0_bstride,
          ptr(x1), ptr(idx1), (x1.stride(0) if x1 is not None else 0),
-         ptr(W), ptr(W2), W.stride(0), ptr(bias), ptr(res), (res.stride(0) if res is not None else 0),
+         ptr(W.data if packed else W), ptr(W2.data if (packed and W2 is not None) else W2), (K if packed else W.stride(0)), ptr(bias), ptr(res),
+         (res.stride(0) if res is not None else 0),
          ptr(out), out.stride(0), M, N, K, epi, ptr(ws), (ws.numel() if ws is not None else 0), stream())
     return out
 
@@ -548,8 +557,11 @@ _head_ws_cache = {}
 def lm_head_topk_into_table(x: torch.Tensor, W: torch.Tensor, k: int, table_idx: torch.Tensor, table_val: torch.Tensor,
                             row0: int, n: int, idx0: Optional[torch.Tensor] = None, M: Optional[int] = None) -> None:
     """top-k(x[idx0] @ W^T) of M = B*n rows written into table[:, row0:row0+n, :] of the [B, R, k] tables, without the logits
-    (eagle_lm_head_topk_rows_bf16: candidates out of the GEMM's epilogue + the final merge)."""
-    _chk(x, "x"), _chk(W, "W")
+    (eagle_lm_head_topk_rows_bf16: candidates out of the GEMM's epilogue + the final merge).  W row-major or a PackedWeight."""
+    _chk(x, "x")
+    packed = isinstance(W, PackedWeight)
+    if not packed:
+        _chk(W, "W")
     N, K = W.shape
     if M is None:
         M = idx0.numel() if idx0 is not None else x.shape[0]
@@ -557,7 +569,7 @@ def lm_head_topk_into_table(x: torch.Tensor, W: torch.Tensor, k: int, table_idx:
     if kk != k or M != B * n or row0 < 0 or row0 + n > R or not table_idx.is_contiguous() or not table_val.is_contiguous() or \
             table_val.shape != table_idx.shape:
         raise ValueError("lm_head_topk_into_table: tables [B, R, k] contiguous, M = B*n rows")
-    if x.stride(-1) != 1 or W.stride(1) != 1 or W.stride(0) != K or x.shape[-1] != K:
+    if x.stride(-1) != 1 or x.shape[-1] != K or (not packed and (W.stride(1) != 1 or W.stride(0) != K)):
         raise ValueError("x rows and W must be contiguous along K")
     if idx0 is not None and (idx0.dtype != torch.int64 or not idx0.is_contiguous()):
         raise TypeError("row index arrays must be contiguous int64")
@@ -569,7 +581,7 @@ def lm_head_topk_into_table(x: torch.Tensor, W: torch.Tensor, k: int, table_idx:
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         _head_ws_cache[key] = ws
-    call("eagle_lm_head_topk_rows_bf16", ptr(x), ptr(idx0), x.stride(0), None, 0, 0, ptr(W), K, None, M, N, K, k,
+    call("eagle_lm_head_topk_rows_bf16", ptr(x), ptr(idx0), x.stride(0), None, 0, 0, ptr(W.data if packed else W), (0 if packed else K), None, M, N, K, k,
          table_idx.data_ptr() + row0 * k * 8, table_val.data_ptr() + row0 * k * 2, n, R * k, ptr(ws), ws.numel(), stream())
 
 

@@ -111,12 +111,12 @@ class EagleDrafter:
         elif self.B > 1 and self.head_topk_fused and self.D % 128 == 0 and \
                 ops.lm_head_topk_rows_ok(rows, self.lm_head.shape[0], self.D, self.k):
             # 81-128 rows of a request batch against a tall head: candidates out of the GEMM's epilogue, no logits
-            ops.lm_head_topk_into_table(x, self.lm_head, self.k, self.flat_ids, self.flat_vals, row0, n, idx0=idx, M=rows)
+            ops.lm_head_topk_into_table(x, self.lm_head_pk, self.k, self.flat_ids, self.flat_vals, row0, n, idx0=idx, M=rows)
             return
         elif self.model.rows_min <= rows <= self.rows_head_max and self.D % 128 == 0:
             # decode batches: the row-batch weight stream (gather fused; 32 rows of the 151936-row head 257 vs 328 us on
             # the LDS-tiled kernels, tools/rows2_bench.py); past ~64 rows its x re-reads cost what the tiles' do
-            logits = ops.linear_rows(x, self.lm_head, idx0=idx, M=rows)
+            logits = ops.linear_rows(x, self.lm_head_pk, idx0=idx, M=rows)
         elif rows >= self.wide_head_rows and self.D % 64 == 0:
             # wide batches: one weight pass on the MFMA GEMM (from 32 rows on it beats the weight-stream kernel, which
             # passes over the weights once per 32 rows: 304 vs 520 us at 32 rows of the 151936-row head)

@@ -28,7 +28,7 @@ typedef struct ihipStream_t* eagle_stream_t; /* == hipStream_t */
  * in the 256 MB Infinity Cache from one draft forward to the next; without it weights stream with non-temporal loads
  * and displace nothing.  A per-call hint (the library keeps no state); it only changes speed, never results. */
 #define EAGLE_GEMM_KEEP_RESIDENT 0x100
-/* OR-ed into `epi` of eagle_gemm_skinny_bf16: W (and W2) point at eagle_pack_weight_bf16 images instead of row-major
+/* OR-ed into `epi` of eagle_gemm_skinny_bf16 and eagle_gemm_rows_bf16 (which then ignores ldw): W (and W2) point at eagle_pack_weight_bf16 images instead of row-major
  * matrices.  Same arithmetic, same output bits; the weight stream then reads whole cache lines (see eagle_pack_weight_bf16). */
 #define EAGLE_GEMM_W_PACKED 0x200
 
@@ -202,7 +202,8 @@ int eagle_topk_merge_candidates(const void* cand, int ncand, int rows, int k, in
  * no second operand) rounds its outputs to bf16 and leaves k candidate records per (row, column tile) in `workspace`
  * (eagle_lm_head_topk_rows_workspace_bytes(M, N, K, k) bytes, 8-byte aligned; 0 = shape not served: the call then returns
  * EAGLE_ERR_SHAPE and the caller takes eagle_gemm_rows_bf16 + eagle_topk_vocab_grouped), eagle_topk_merge_candidates
- * finishes.  Ids identical to that two-step path (same bf16 rounding, same order: value, then lowest index). */
+ * finishes.  Ids identical to that two-step path (same bf16 rounding, same order: value, then lowest index).
+ * ldw == 0: W is an eagle_pack_weight_bf16 image. */
 int64_t eagle_lm_head_topk_rows_workspace_bytes(int M, int N, int K, int k);
 int eagle_lm_head_topk_rows_bf16(const void* x0, const int64_t* idx0, int64_t ld0, const int64_t* ind0, int ind_n,
                                  int64_t idx0_bstride, const void* W, int64_t ldw, const void* bias,

@@ -117,6 +117,37 @@ def test_lm_head_topk_without_logits(B, n, N, K):
     assert torch.equal(tv[:, 2:2 + n].reshape(M, k).float(), ev)
 
 
+@pytest.mark.parametrize("M,N,K", [(17, 4096, 4096), (32, 12288, 4096), (64, 4096, 8192), (96, 4096, 12288), (128, 4096, 4096), (128, 151936, 4096),
+                                   (96, 70000, 256), (20, 1000, 256), (128, 200, 384), (50, 72, 1024), (192, 4096, 4096), (150, 12288, 4096),
+                                   (128, 12200, 512), (100, 33001, 384)])
+def test_gemm_rows_packed_weights_are_bit_equal(M, N, K):
+    """eagle_gemm_rows_bf16 over eagle_pack_weight_bf16 images (whole-cache-line weight reads) against the same call over
+    the row-major matrix: both forms of the kernel (4 + loader waves; the 8-wave many-tile form), split and unsplit K, ragged
+    N, bias + residual, SiLU*up, gathered rows -- identical output bits (same tiles, same K order)."""
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(M * 31 + N + K)
+    x = torch.randn(M, K, generator=g).to(BF).to(dev())
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(dev())
+    b = torch.randn(N, generator=g).to(BF).to(dev())
+    r = torch.randn(M, N, generator=g).to(BF).to(dev())
+    Wp = ops.pack_weight(W)
+    assert torch.equal(ops.linear_rows(x, Wp), ops.linear_rows(x, W))
+    assert torch.equal(ops.linear_rows(x, Wp, bias=b, res=r), ops.linear_rows(x, W, bias=b, res=r))
+    idx = torch.randperm(M, generator=g).to(dev())
+    assert torch.equal(ops.linear_rows(x, Wp, idx0=idx, M=M), ops.linear_rows(x, W, idx0=idx, M=M))
+    if N % 32 == 0 and N <= 24576:
+        I = N // 2                                                    # stacked gate|up: W2 a view of the row-major matrix
+        gp, up = ops.pack_weight(W[:I]), ops.pack_weight(W[I:])
+        assert torch.equal(ops.linear_rows(x, gp, W2=up), ops.linear_rows(x, W[:I], W2=W[I:]))
+    if ops.lm_head_topk_rows_ok(M, N, K, 10):
+        B, n = (M // 4, 4) if M % 4 == 0 else (M, 1)
+        t0 = torch.zeros((B, n, 10), dtype=torch.int64, device=dev()); v0 = torch.zeros((B, n, 10), dtype=BF, device=dev())
+        t1, v1 = t0.clone(), v0.clone()
+        ops.lm_head_topk_into_table(x, W, 10, t0, v0, 0, n, M=M)
+        ops.lm_head_topk_into_table(x, Wp, 10, t1, v1, 0, n, M=M)
+        assert torch.equal(t0, t1) and torch.equal(v0, v1)
+
+
 def test_lm_head_topk_shapes_outside_the_wide_form_are_refused():
     from eagle_amd import ops
     assert not ops.lm_head_topk_rows_ok(32, 151936, 4096, 10)      # 32 rows: the register-resident stream's case
