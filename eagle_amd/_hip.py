@@ -90,6 +90,7 @@ SIGNATURES = {
     "eagle_debug_set_rows": (None, [I, I, I]),
     "eagle_debug_set_attn": (None, [I]),
     "eagle_debug_set_topk": (None, [I]),
+    "eagle_debug_set_loss": (None, [I]),
 }
 
 _lib = None

@@ -52,6 +52,26 @@ __device__ __forceinline__ void merge_o(OState& x, const OState& y) {
   }
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int ce_u32x4;
+// The logits are read once per pass and are far larger than the Infinity Cache (2 x 1.24 GB at N = 4096, V = 151936):
+// non-temporal 16-byte loads (tools/stream_probe.hip: whole-line reads stream at 6.0 TB/s with the default policy, 6.6 TB/s
+// non-temporal).  NT = false keeps the default policy (diagnostics, eagle_debug_set_loss).
+template <bool NT> __device__ __forceinline__ uint4 ce_ld16(const bf16_t* p) {
+  if (NT) {
+    const ce_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const ce_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  }
+  return *reinterpret_cast<const uint4*>(p);
+}
+template <bool NT> __device__ __forceinline__ void ce_st16(bf16_t* p, const uint4& v) {
+  if (NT) {
+    ce_u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<ce_u32x4*>(p));
+  } else {
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+}
+
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
   const uint32_t* u = reinterpret_cast<const uint32_t*>(&v);
 #pragma unroll
@@ -91,6 +111,7 @@ __device__ __forceinline__ void absorb(TState& ts, OState& os, const float* tf, 
 }
 
 // grid: N rows.  t/o: [N, V] bf16 with row stride ld (elements); v0 = global index of column 0.
+template <bool NT, int UNROLL>
 __global__ __launch_bounds__(CE_THREADS) void ce_partial_kernel(const bf16_t* __restrict__ t, const bf16_t* __restrict__ o,
                                                                int64_t ld, int V, int v0,
                                                                const bf16_t* __restrict__ predict,
@@ -108,9 +129,24 @@ __global__ __launch_bounds__(CE_THREADS) void ce_partial_kernel(const bf16_t* __
   float tf[8], of[8];
   if (vec) {
     const int nfull = V >> 3;
-    for (int c = threadIdx.x; c < nfull; c += CE_THREADS) {
-      const uint4 tv = *reinterpret_cast<const uint4*>(tr + c * 8);
-      const uint4 ov = *reinterpret_cast<const uint4*>(orow + c * 8);
+    int c = threadIdx.x;
+    // UNROLL chunk pairs per thread in flight before the first is absorbed
+    for (; c + (UNROLL - 1) * CE_THREADS < nfull; c += UNROLL * CE_THREADS) {
+      uint4 tv[UNROLL], ov[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        tv[u] = ce_ld16<NT>(tr + (c + u * CE_THREADS) * 8);
+        ov[u] = ce_ld16<NT>(orow + (c + u * CE_THREADS) * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        unpack8(tv[u], tf); unpack8(ov[u], of);
+        absorb(ts, os, tf, of, 8, v0 + (c + u * CE_THREADS) * 8);
+      }
+    }
+    for (; c < nfull; c += CE_THREADS) {
+      const uint4 tv = ce_ld16<NT>(tr + c * 8);
+      const uint4 ov = ce_ld16<NT>(orow + c * 8);
       unpack8(tv, tf); unpack8(ov, of);
       absorb(ts, os, tf, of, 8, v0 + c * 8);
     }
@@ -208,6 +244,7 @@ __global__ __launch_bounds__(1024) void ce_combine_kernel(const CeStat* __restri
 
 // dlogits[n][v] = mask[n] * g_p * (softmax(o) - softmax(t));  dpred_v[n][d] = mask[n]*g_v*clamp(p-t,-1,1)/D
 // grid: N rows.  May run in place (dlogits == o).
+template <bool NT, bool NTS, int UNROLL>
 __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const bf16_t* __restrict__ t, const bf16_t* o,
                                                            int64_t ld, int V, const float* __restrict__ lse_t,
                                                            const float* __restrict__ lse_o, const float* __restrict__ mask,
@@ -226,12 +263,12 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const bf16_t* __rest
   if (vec) {
     const int nfull = V >> 3;
     if (gp == 0.f) {
-      for (int c = threadIdx.x; c < nfull; c += CE_THREADS) *reinterpret_cast<uint4*>(dr + c * 8) = make_uint4(0, 0, 0, 0);
+      for (int c = threadIdx.x; c < nfull; c += CE_THREADS) ce_st16<NTS>(dr + c * 8, make_uint4(0, 0, 0, 0));
     } else {
-      for (int c = threadIdx.x; c < nfull; c += CE_THREADS) {
+      auto one = [&](const uint4& tv, const uint4& ov, int c) {
         float tf[8], of[8];
-        unpack8(*reinterpret_cast<const uint4*>(tr + c * 8), tf);
-        unpack8(*reinterpret_cast<const uint4*>(orow + c * 8), of);
+        unpack8(tv, tf);
+        unpack8(ov, of);
         uint4 dv;
         uint32_t* du = reinterpret_cast<uint32_t*>(&dv);
 #pragma unroll
@@ -240,8 +277,21 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const bf16_t* __rest
           const float d1 = gp * (exp2f(fmaf(of[2 * j + 1], L2E, bo)) - exp2f(fmaf(tf[2 * j + 1], L2E, bt)));
           du[j] = pack2bf(d0, d1);
         }
-        *reinterpret_cast<uint4*>(dr + c * 8) = dv;
+        ce_st16<NTS>(dr + c * 8, dv);
+      };
+      int c = threadIdx.x;
+      // in place (dlogits == o) is safe: every thread stores the chunks it has loaded, and only after loading them
+      for (; c + (UNROLL - 1) * CE_THREADS < nfull; c += UNROLL * CE_THREADS) {
+        uint4 tv[UNROLL], ov[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+          tv[u] = ce_ld16<NT>(tr + (c + u * CE_THREADS) * 8);
+          ov[u] = ce_ld16<NT>(orow + (c + u * CE_THREADS) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) one(tv[u], ov[u], c + u * CE_THREADS);
       }
+      for (; c < nfull; c += CE_THREADS) one(ce_ld16<NT>(tr + c * 8), ce_ld16<NT>(orow + c * 8), c);
     }
     for (int v = nfull * 8 + threadIdx.x; v < V; v += CE_THREADS)
       dr[v] = gp == 0.f ? (bf16_t)0 : f2bf(gp * (exp2f(fmaf(bf2f(orow[v]), L2E, bo)) - exp2f(fmaf(bf2f(tr[v]), L2E, bt))));
@@ -272,13 +322,24 @@ __global__ __launch_bounds__(CE_THREADS) void ce_bwd_kernel(const bf16_t* __rest
 
 extern "C" int eagle_ce_stat_bytes() { return (int)sizeof(CeStat); }
 
+// Default (measured, tools/loss_bw.py, N = 2048 x V = 151936): non-temporal logit loads, non-temporal dlogits stores, four
+// 16-byte chunk pairs per thread in flight -- forward 260 -> 247 us, backward 393 -> 367 us against round 2's form (default
+// policy, one pair in flight).  Diagnostics: bit 0 = default-policy logit loads, bit 1 = one chunk pair in flight,
+// bit 2 = default-policy dlogits stores, bit 4 = two chunk pairs in flight.
+static int g_loss_variant = 0;
+extern "C" void eagle_debug_set_loss(int v) { g_loss_variant = v; }
+
 extern "C" int eagle_ce_partial_bf16(const void* t_logits, const void* o_logits, int64_t ld, int N, int V, int v0,
                                      const void* predict, const void* target, int D, void* stats, hipStream_t stream) {
   if (!t_logits || !o_logits || !stats) return EAGLE_ERR_ARG;
   if (N < 1 || V < 1 || ld < V) return EAGLE_ERR_SHAPE;
   if (predict && (!target || D < 8 || (D & 7))) return EAGLE_ERR_SHAPE;
-  hipLaunchKernelGGL(ce_partial_kernel, dim3(N), dim3(CE_THREADS), 0, stream, (const bf16_t*)t_logits, (const bf16_t*)o_logits,
-                     ld, V, v0, (const bf16_t*)predict, (const bf16_t*)target, D, (CeStat*)stats);
+  const int un = (g_loss_variant & 2) ? 1 : (g_loss_variant & 16) ? 2 : 4;
+#define CE_FWD(NT_, UN_) hipLaunchKernelGGL((ce_partial_kernel<NT_, UN_>), dim3(N), dim3(CE_THREADS), 0, stream, (const bf16_t*)t_logits, \
+                     (const bf16_t*)o_logits, ld, V, v0, (const bf16_t*)predict, (const bf16_t*)target, D, (CeStat*)stats)
+  if (g_loss_variant & 1) { if (un == 1) CE_FWD(false, 1); else if (un == 4) CE_FWD(false, 4); else CE_FWD(false, 2); }
+  else { if (un == 1) CE_FWD(true, 1); else if (un == 4) CE_FWD(true, 4); else CE_FWD(true, 2); }
+#undef CE_FWD
   return eagle_check_launch();
 }
 
@@ -298,9 +359,16 @@ extern "C" int eagle_ce_smoothl1_bwd_bf16(const void* t_logits, const void* o_lo
   if (!t_logits || !o_logits || !lse_t || !lse_o || !dlogits) return EAGLE_ERR_ARG;
   if (N < 1 || V < 1 || ld < V || ldd < V) return EAGLE_ERR_SHAPE;
   if (dpredict && (!predict || !target || D < 8 || (D & 7))) return EAGLE_ERR_SHAPE;
-  hipLaunchKernelGGL(ce_bwd_kernel, dim3(N), dim3(CE_THREADS), 0, stream, (const bf16_t*)t_logits, (const bf16_t*)o_logits, ld,
-                     V, lse_t, lse_o, mask, g_p, g_v, (bf16_t*)dlogits, ldd, (const bf16_t*)predict, (const bf16_t*)target, D,
-                     (bf16_t*)dpredict);
+  const int un = (g_loss_variant & 2) ? 1 : (g_loss_variant & 16) ? 2 : 4;
+#define CE_BWD(NT_, NTS_, UN_) hipLaunchKernelGGL((ce_bwd_kernel<NT_, NTS_, UN_>), dim3(N), dim3(CE_THREADS), 0, stream, (const bf16_t*)t_logits, \
+                     (const bf16_t*)o_logits, ld, V, lse_t, lse_o, mask, g_p, g_v, (bf16_t*)dlogits, ldd, (const bf16_t*)predict,       \
+                     (const bf16_t*)target, D, (bf16_t*)dpredict)
+  const bool nt = !(g_loss_variant & 1), nts = !(g_loss_variant & 4);
+  if (nt && !nts) { if (un == 1) CE_BWD(true, false, 1); else if (un == 4) CE_BWD(true, false, 4); else CE_BWD(true, false, 2); }
+  else if (nt && nts) { if (un == 1) CE_BWD(true, true, 1); else if (un == 4) CE_BWD(true, true, 4); else CE_BWD(true, true, 2); }
+  else if (!nt && !nts) { if (un == 1) CE_BWD(false, false, 1); else if (un == 4) CE_BWD(false, false, 4); else CE_BWD(false, false, 2); }
+  else { if (un == 1) CE_BWD(false, true, 1); else if (un == 4) CE_BWD(false, true, 4); else CE_BWD(false, true, 2); }
+#undef CE_BWD
   return eagle_check_launch();
 }
 

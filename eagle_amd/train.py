@@ -14,9 +14,10 @@ Two ways in, both ending in the same HIP kernel chains (include/eagle_hip.h):
 No [B,H,L,L] score tensor, no softmax / log-softmax tensors and no fp32 mask are ever
 materialised; the only [N,V] tensors are the two bf16 logit buffers, and dlogits overwrites one.
 
-Backward GEMMs run on the same NT MFMA kernel as the forward: dgrad uses the transposed weight
-(cached per weight version), wgrad the transposed activations (eagle_transpose_bf16); both
-transposes are bandwidth passes worth ~1 % of the GEMM time at 4096 tokens.
+Backward GEMMs run on the 256x256 MFMA kernel's K-major operand forms: the data gradients read the weights as the
+state_dict stores them (eagle_gemm_nn_bf16), the weight gradients read dY and X as they lie in memory
+(eagle_gemm_tn_bf16) -- no transposed weights or activations exist (only the frozen lm_head keeps a transposed copy, built
+once); shapes outside those kernels' range fall back to eagle_transpose_bf16 + the NT kernel.
 """
 from __future__ import annotations
 

@@ -82,8 +82,9 @@ int eagle_gemm_rows_bf16(const void* x0, const int64_t* idx0, int64_t ld0, int K
  * for training-size M.  (+bias[N]) (+res[M,N] bf16); C is bf16 (out_f32 = 0) or fp32 (1);
  * accumulate != 0: C += result.  K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned bases.
  * Replaces the nn.Linear forward GEMMs of eagle/llama2.py:222-224,:280,:317,:542 and of the frozen
- * lm_head (eagle/train.py:107,:110) at training sizes, and (with eagle_transpose_bf16 on the
- * operands) their autograd backward GEMMs behind loss.backward() (eagle/train.py:126). */
+ * lm_head (eagle/train.py:107,:110) at training sizes.  Their autograd backward GEMMs behind loss.backward()
+ * (eagle/train.py:126) run on eagle_gemm_nn_bf16 / eagle_gemm_tn_bf16 below (operands as they lie in memory); this entry
+ * point with eagle_transpose_bf16 on the operands serves the shapes those two do not take. */
 int eagle_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                        const void* bias, const void* res, int64_t ldr, int M, int N, int K,
                        int out_f32, int accumulate, eagle_stream_t stream);
@@ -108,8 +109,9 @@ int eagle_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, v
  * 16-byte aligned bases; K * ldb * 2 < 4 GiB.  C bf16 (out_f32 = 0) or fp32; accumulate: C += . */
 int eagle_gemm_nn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* res,
                        int64_t ldr, int M, int N, int K, int out_f32, int accumulate, eagle_stream_t stream);
-/* out[C,R_pad] = in[R,C]^T, bf16, columns [R, R_pad) zero-filled (R_pad < R: no padding): operand
- * preparation for the dgrad / wgrad GEMMs behind loss.backward() (eagle/train.py:126); the zero
+/* out[C,R_pad] = in[R,C]^T, bf16, columns [R, R_pad) zero-filled (R_pad < R: no padding): builds the transposed copy of
+ * the frozen lm_head once, and prepares operands for the dgrad / wgrad GEMMs behind loss.backward() (eagle/train.py:126)
+ * at shapes eagle_gemm_nn_bf16 / eagle_gemm_tn_bf16 do not take (no training step at the shipped dims needs it); the zero
  * padding lets a token count that is no multiple of 64 serve as the GEMM's K.  ldo >= R_pad. */
 int eagle_transpose_bf16(const void* in, int64_t ldi, void* out, int64_t ldo, int R, int C, int R_pad,
                          eagle_stream_t stream);
@@ -416,6 +418,10 @@ void eagle_debug_set_attn(int no_head_packing);
  * (a 16-wave workgroup per row, candidates in LDS) for every bf16 call of up to 65536 columns; 0 = default: one launch
  * for k <= 2 (the greedy argmax), two otherwise. */
 void eagle_debug_set_topk(int two_stage);
+/* eagle_ce_partial_bf16 / eagle_ce_smoothl1_bwd_bf16: bit 0 = default-policy logit loads (default: non-temporal), bit 1 = one
+ * 16-byte chunk pair per thread in flight (default: four), bit 2 = default-policy dlogits stores (default: non-temporal),
+ * bit 4 = two chunk pairs in flight. */
+void eagle_debug_set_loss(int variant);
 /* eagle_gemm_rows_bf16: target_wg > 0 = workgroups the K split aims for (0 = by shape), min_steps = least 128-wide K
  * super-steps per slice (default 4); stages: bits 0-3 = 2 / 3 / 4 weight register stages (0 = default 3), bits 4-7 =
  * 1 + K-walk stagger of neighbouring column tiles (0 = default stagger 1), bit 8 = sum the partial sums inside the launch (last workgroup of a tile to arrive) instead of in a second launch,
