@@ -56,14 +56,16 @@ def loss_roofline(dev, N: int, V: int, D: int, iters: int = 8) -> dict:
     b_f, b_b = 2.0 * N * V * 2 + 2.0 * N * D * 2, 3.0 * N * V * 2 + 3.0 * N * D * 2
     ach = (b_f + b_b) / (t_f + t_b) / 1e9
     # HBM bytes of one forward + one backward from rocprofv3 PMC passes of the same kernels at this shape
-    # (profiles/r01_loss_pmc.json: tools/gpu_profile2.sh + tools/pmc2_to_json.py), else null
+    # (profiles/r0x_loss_pmc.json, newest first: tools/gpu_profile_r03.sh + tools/pmc2_to_json.py), else null
     traffic = None
-    pj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_loss_pmc.json")
-    if os.path.exists(pj):
-        with open(pj) as f:
-            pm = json.load(f)
-        if pm.get("shape") == {"N": N, "V": V, "D": D}:
-            traffic = pm.get("traffic_bytes_fwd_plus_bwd")
+    for name in ("r03_loss_pmc.json", "r01_loss_pmc.json"):
+        pj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
+        if os.path.exists(pj):
+            with open(pj) as f:
+                pm = json.load(f)
+            if pm.get("shape") == {"N": N, "V": V, "D": D}:
+                traffic = pm.get("traffic_bytes_fwd_plus_bwd")
+            break
     return {"bound": "hbm", "kernel": "ce_partial_kernel + ce_combine_kernel (fwd), ce_bwd_kernel (bwd)", "achieved": ach,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_fwd_plus_bwd": b_f + b_b,

@@ -45,18 +45,15 @@ WIDE_CASES = [
 ]
 
 
-@pytest.mark.parametrize("B,M,H,HK,use_tree,extra", WIDE_CASES)
-def test_wide_batch_attention_against_the_oracle(B, M, H, HK, use_tree, extra):
-    """eagle_tree_attention_bf16 at B.H >= 256 (RoPE/append pre-pass + attn_wide_kernel with P.V on MFMA + combine) against
-    oracle.draft_model.attention_core (eagle/llama2.py:226-273 with the mask of :460-491) request by request: ragged pasts
-    incl. 0, 511, 512 and > 512 keys; appended K/V rows bit for bit, outputs to close()."""
+def _attention_against_the_oracle(B, M, H, HK, use_tree, extra, base, max_kv, what):
+    """eagle_tree_attention_bf16 on seeded q|k|v rows and caches against oracle.draft_model.attention_core request by request:
+    appended K/V rows bit for bit, rows outside the append untouched, outputs to close() and rel-L2 < 1e-2."""
     from eagle_amd import ops
-    assert B * H >= 256, "this shape would run the split-KV kernel"
     d = dev()
     hd, cap = 128, 1024
-    g = torch.Generator().manual_seed(B * 1000 + M * 10 + H + HK)
-    base = [0, 511, 512, 700, 5, 63, 64, 300, 37, 1, 129, 513]
+    g = torch.Generator().manual_seed(B * 1000 + M * 10 + H + HK + max_kv)
     past = torch.tensor([base[b % len(base)] + (b // len(base)) * 7 + extra for b in range(B)], dtype=torch.int32)
+    assert int(past.max()) + M <= max_kv <= cap
     qkv = (torch.randn(B * M, (H + 2 * HK) * hd, generator=g) * 0.8).to(BF)
     kc = torch.randn(B, HK, cap, hd, generator=g).to(BF)
     vc = torch.randn(B, HK, cap, hd, generator=g).to(BF)
@@ -69,10 +66,10 @@ def test_wide_batch_attention_against_the_oracle(B, M, H, HK, use_tree, extra):
         tm[torch.arange(M), extra + torch.arange(M)] = 1            # every row sees itself
     err = torch.zeros(1, dtype=torch.int32, device=d)
     out = torch.zeros((B * M, H * hd), dtype=BF, device=d)
-    ws = torch.empty(ops.query("eagle_attn_decode_workspace_bytes", B, H, cap), dtype=torch.uint8, device=d)
+    ws = torch.empty(ops.query("eagle_attn_decode_workspace_bytes", B, H, max_kv), dtype=torch.uint8, device=d)
     kd, vd = kc.to(d), vc.to(d)
     ops.tree_attention(qkv.to(d), None, cos_d, sin_d, kd, vd, past.to(d), 0, None if tm is None else tm.to(d).contiguous(), None,
-                       out, ws, err, B, M, H, HK, hd, cap, True, M, 0, pos_off=0, pos_stride=0 if use_tree else 1)
+                       out, ws, err, B, M, H, HK, hd, max_kv, True, M, 0, pos_off=0, pos_stride=0 if use_tree else 1)
     assert int(err.item()) == 0
     out, kd, vd = out.cpu(), kd.cpu(), vd.cpu()
     dims = dm.DraftDims(hidden=H * hd, heads=H, kv_heads=HK)
@@ -89,9 +86,41 @@ def test_wide_batch_attention_against_the_oracle(B, M, H, HK, use_tree, extra):
         assert torch.equal(kd[b, :, p:p + M], kk[0, :, p:]), f"request {b}: appended K rows differ from the oracle's RoPE"
         assert torch.equal(vd[b, :, p:p + M], vv[0, :, p:]), f"request {b}: appended V rows differ"
         assert torch.equal(kd[b, :, :p], kc[b, :, :p]) and torch.equal(kd[b, :, p + M:], kc[b, :, p + M:]), "rows outside the append touched"
-        close(out[b * M:(b + 1) * M], o[0], what="wide attention vs oracle")
+        close(out[b * M:(b + 1) * M], o[0], what=what)
         worst = max(worst, rel_l2(out[b * M:(b + 1) * M], o[0]))
     assert worst < 1e-2, f"relative L2 error {worst:.3g}"
+
+
+@pytest.mark.parametrize("B,M,H,HK,use_tree,extra", WIDE_CASES)
+def test_wide_batch_attention_against_the_oracle(B, M, H, HK, use_tree, extra):
+    """eagle_tree_attention_bf16 at B.H >= 256 (RoPE/append pre-pass + attn_wide_kernel with P.V on MFMA + combine) against
+    oracle.draft_model.attention_core (eagle/llama2.py:226-273 with the mask of :460-491) request by request: ragged pasts
+    incl. 0, 511, 512 and > 512 keys; appended K/V rows bit for bit, outputs to close()."""
+    assert B * H >= 256, "this shape would run the split-KV kernel"
+    _attention_against_the_oracle(B, M, H, HK, use_tree, extra, [0, 511, 512, 700, 5, 63, 64, 300, 37, 1, 129, 513], 1024,
+                                  "wide attention vs oracle")
+
+
+NARROW_CASES = [
+    # B, M, H, HK, tree, extra tree columns, key bound
+    (1, 4, 32, 32, True, 0, 704),      # the batch-1 tree step of the bench (cycle bound 704 keys)
+    (1, 6, 32, 32, False, 0, 704),     # the catch-up forward
+    (1, 4, 32, 32, True, 3, 512),      # a mask that covers earlier tree rows
+    (1, 8, 32, 32, True, 0, 1024),     # a dynamic-tree step: 8 rows
+    (1, 1, 32, 32, False, 0, 1024),    # q_len 1
+    (5, 4, 32, 8, True, 0, 1024),      # a narrow ragged batch, grouped-query heads
+    (3, 16, 16, 8, False, 0, 384),     # a full 16-row block
+    (2, 2, 2, 2, True, 0, 256),        # the tiny test models' head count
+]
+
+
+@pytest.mark.parametrize("B,M,H,HK,use_tree,extra,max_kv", NARROW_CASES)
+def test_split_kv_attention_against_the_oracle(B, M, H, HK, use_tree, extra, max_kv):
+    """The split-KV kernel pair of narrow batches (B.H < 256: every batch-1 tree step) against the oracle at real head
+    dims, with the same bar as the wide-batch kernel above."""
+    base = [p for p in [0, 5, 63, 64, 300, 37, 1, 129, 250, 500, 700, 1000] if p + M + extra + 14 <= max_kv]
+    assert B * H < 256
+    _attention_against_the_oracle(B, M, H, HK, use_tree, extra, base, max_kv, "split-KV attention vs oracle")
 
 
 @pytest.mark.parametrize("HK", [8, 2])

@@ -20,4 +20,10 @@ timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 tools/prof_lm_head.py > $OUT/pmc_write.log 2>&1
 python3 tools/pmc_to_json.py $OUT $OUT/lm_head_pmc.json > /dev/null
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+# fused loss kernels (HBM traffic) and the training lm_head GEMM (MFMA pipe occupancy): refreshed every round
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_loss_fetch -- python3 tools/prof_loss.py > $OUT/pmc_loss_fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_loss_write -- python3 tools/prof_loss.py > $OUT/pmc_loss_write.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_gemm -- python3 tools/prof_gemm.py > $OUT/pmc_gemm.log 2>&1
+timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_gemm -- python3 tools/prof_gemm.py > $OUT/trace_gemm.log 2>&1
+python3 tools/pmc2_to_json.py $OUT $OUT/r03 > /dev/null
 tail -c 600 $OUT/bench.json

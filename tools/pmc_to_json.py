@@ -24,11 +24,13 @@ write = per_launch(root + "/pmc_write", "WRITE_SIZE")
 traffic = (sum(fetch) / len(fetch) * 2 + sum(write) / len(write)) * 1024
 alg = V * D * 2 + ROWS * D * 2 + ROWS * V * 2
 json.dump({
-    "kernel": "gemm_skinny_keepx_kernel<1,0,4> (lm_head, %d rows x %d x %d bf16)" % (ROWS, V, D),
+    "kernel": "gemm_skinny_keepx_kernel<1,0,4,...,packed> (lm_head, %d rows x %d x %d bf16, packed weight image)" % (ROWS, V, D),
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 tools/prof_lm_head.py (separate passes)",
     "FETCH_SIZE_KB_per_launch": fetch,
     "WRITE_SIZE_KB_per_launch": write,
-    "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; unit KiB",
+    "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; unit KiB.  "
+                  "Round 3 (profiles/r03_lm_head_fetch_variants.txt): the rule holds when every request is a whole line, as with the packed image; the row-major "
+                  "fragment shape sends half-line requests that the counter tallies at full size, which read as 8.5 % 'over-fetch' in round 2",
     "traffic_bytes_per_launch": traffic,
     "algorithmic_bytes_per_launch": alg,
     "traffic_over_algorithmic": traffic / alg,

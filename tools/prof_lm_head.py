@@ -1,5 +1,5 @@
 """PMC target: N launches of the dominant decode kernel (the lm_head weight stream of bench.py's
-`roofline`: gemm_skinny_keepx_kernel<1,0,4>, 4 rows x 32000 x 4096 bf16) and nothing else of note, so that
+`roofline`: gemm_skinny_keepx_kernel<1,0,4,...,PK>, 4 rows x 32000 x 4096 bf16 over the packed image) and nothing else of note, so that
 rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE rows of that kernel can be read per launch.
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 tools/prof_lm_head.py
 """
@@ -19,8 +19,9 @@ x = torch.randn((rows, D), generator=g, device=dev).to(torch.bfloat16)
 out = torch.empty((rows, V), device=dev, dtype=torch.bfloat16)
 # a 1 GiB scrub between launches keeps the 256 MiB Infinity Cache from serving the re-read
 scrub = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+Wp = ops.pack_weight(W)          # what the drafter streams: the packed image (whole-cache-line reads)
 for i in range(6):
     scrub.fill_(float(i))
-    ops.linear_skinny(x, W, out=out)
+    ops.linear_skinny(x, Wp if "--row-major" not in sys.argv else W, out=out)
 torch.cuda.synchronize()
 print("done", float(out.float().abs().mean()))
