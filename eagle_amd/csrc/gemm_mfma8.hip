@@ -470,6 +470,8 @@ __global__ __launch_bounds__(256) void gemm8_reduce_kernel(Gemm8Args p) {
   }
 }
 
+extern int g_gemm8_gm;
+static int g8_gm(int tiles_m) { const int want = g_gemm8_gm > 0 ? g_gemm8_gm : 8; return tiles_m < want ? tiles_m : want; }
 // Called by eagle_gemm_nt_bf16 (gemm_mfma.hip) after its argument checks.
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                           const void* res, int64_t ldr, int M, int N, int K, int out_f32, int accumulate, int ksplit,
@@ -487,7 +489,7 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
   a.bias = (const bf16_t*)bias; a.res = (const bf16_t*)res; a.ldr = ldr;
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
   a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = (N + G8_BN - 1) / G8_BN;
-  a.gm = a.tiles_m < 8 ? a.tiles_m : 8;             // row tiles per group of the grouped tile order
+  a.gm = g8_gm(a.tiles_m);                          // row tiles per group of the grouped tile order
   a.tn = 0;
   hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
   int rc = eagle_check_launch();
@@ -513,7 +515,7 @@ extern "C" int eagle_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
   a.tiles_m = M / G8_BM; a.tiles_n = N / G8_BN;
   a.ksplit = 1; a.kchunk = K / G8_BK; a.partial = nullptr;
-  a.gm = a.tiles_m < 8 ? a.tiles_m : 8;
+  a.gm = g8_gm(a.tiles_m);
   a.tn = 1;
   hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, true, true>), dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
   return eagle_check_launch();
@@ -536,7 +538,7 @@ extern "C" int eagle_gemm_nn_bf16(const void* A, int64_t lda, const void* B, int
   a.M = M; a.N = N; a.K = K; a.out_f32 = out_f32; a.accumulate = accumulate;
   a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = N / G8_BN;
   a.ksplit = 1; a.kchunk = K / G8_BK; a.partial = nullptr;
-  a.gm = a.tiles_m < 8 ? a.tiles_m : 8;
+  a.gm = g8_gm(a.tiles_m);
   a.tn = 1;
   hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
   return eagle_check_launch();
