@@ -21,6 +21,7 @@
 //     ([N/16][K/32][64 lanes][8 bf16]), so the same registers are filled by whole-line reads; the arithmetic (and therefore
 //     every output bit) is unchanged.
 #include "common.h"
+#include <type_traits>
 
 #define SK_WAVES 8
 #define EPI_LINEAR 0     // (+bias) (+residual)
@@ -558,7 +559,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   }
 
   f32x4 acc[MT][RT];
-  for (int ts = 0; ts < n_ts; ++ts) {
+  // One tile-step.  LAST (the block's final one): no refill past the block's rows -- with packed images those refills would
+  // re-read the last tile's 1 KiB pieces from HBM (non-temporal lines do not stay): 64 KB per block, 6 % of the lm_head's bytes and
+  // 16 % of q|k|v's (PMC, profiles/r03_lm_head_pmc.json); a peeled copy instead of a guarded load keeps hipcc's vmcnt counts exact.
+  auto tile_step = [&](const int ts, auto last_c) {
+    constexpr bool LAST = decltype(last_c)::value;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -572,8 +577,8 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[it % S][s][t], xk[mt][it][s], acc[mt][t], 0, 0, 0);
-      // refill this stage with the super-step S ahead (past the last tile-step: clamped rows)
-      load_w(a[it % S], ts + (it + S) / NI, (it + S) % NI);
+      // refill this stage with the super-step S ahead
+      if (!(LAST && it + S >= NI)) load_w(a[it % S], ts + (it + S) / NI, (it + S) % NI);
     }
     const int parity = ts & 1;
 #pragma unroll
@@ -616,13 +621,11 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
                 y[r] = v;
               }
             }
+            bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
             if (stage_out) {                       // columns past row_hi are staged too and never copied out
               uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
               *reinterpret_cast<uint2*>(&ost[m][nb - row_lo]) = v;
-              continue;
-            }
-            bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
-            if (nb + 3 < row_hi && ((p.ldo | nb) & 3) == 0) {
+            } else if (nb + 3 < row_hi && ((p.ldo | nb) & 3) == 0) {
               uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
               *reinterpret_cast<uint2*>(o) = v;
             } else {
@@ -632,7 +635,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
         }
       }
     }
-  }
+  };
+  for (int ts = 0; ts + 1 < n_ts; ++ts) tile_step(ts, std::false_type{});
+  tile_step(n_ts - 1, std::true_type{});
   if (!stage_out) return;
   __syncthreads();
   const int ncols = row_hi - row_lo, cpr = (ncols + 7) >> 3;        // 16-byte chunks per row

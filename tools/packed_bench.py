@@ -46,5 +46,5 @@ for name, (N, K) in shapes.items():
         res[packed] = ts[len(ts) // 2]
     mb = N * K * 2 * (2 if W2 is not None else 1) / 1e6
     total[False] += res[False]; total[True] += res[True]
-    print(f"{name:14s} {mb:7.1f} MB  row-major {res[False]:6.1f} us ({mb / res[False] / 1e3:5.2f} TB/s)   packed {res[True]:6.1f} us ({mb / res[True] / 1e3:5.2f} TB/s)", flush=True)
+    print(f"{name:14s} {mb:7.1f} MB  row-major {res[False]:6.1f} us ({mb / res[False]:5.2f} TB/s)   packed {res[True]:6.1f} us ({mb / res[True]:5.2f} TB/s)", flush=True)
 print(f"sum over one forward: row-major {total[False]:.1f} us, packed {total[True]:.1f} us")
