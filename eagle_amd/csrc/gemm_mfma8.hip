@@ -34,6 +34,9 @@
 #ifndef G8_PRIO_M
 #define G8_PRIO_M 1
 #define G8_PRIO_R 0
+#ifndef G8_SCHED
+#define G8_SCHED 2
+#endif
 #endif
 #define G8_HALF (128 * G8_BK)           // elements per half-tile (16 KB)
 
@@ -137,7 +140,7 @@ __device__ __forceinline__ void g8_stage(const G8Src& s, int h, int kt, bf16_t* 
 }
 
 // TA / TB: operand A / B is stored K-major ([K, M] / [K, N]) and read through transposing LDS reads
-template <bool PINGPONG, int DBG = 0, bool TA = false, bool TB = false>
+template <bool PINGPONG, int DBG = 0, bool TA = false, bool TB = false, int SCHED = G8_SCHED>
 __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
   // ONE shared array (a second LDS object makes hipcc drain the DMA before every ds_read):
   // [buffer 2][A0, A1, B0, B1][128 x 64]  = 128 KB
@@ -245,15 +248,39 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
     // bit 2 = no barriers, bit 3 = DMA always from the first two K tiles (cache-hot), bit 4 = no vmcnt wait, bit 6 = no output stores
 #define G8_BAR() do { if (!(DBG & 4)) __builtin_amdgcn_s_barrier(); } while (0)
     if (DBG & 2) { read_b(hbuf(0, 2 + (wc >> 1)), 0, bf0); read_a(hbuf(0, wr), 0); read_b(hbuf(0, 2 + (wc >> 1)), 1, bf1); }
+    if (SCHED == 2) {
+      // four slots per K tile: 32 MFMAs per M slot, half the barriers; every R slot ends with its LDS reads retired
+      for (int t = 0; t < nk; ++t) {
+        const bf16_t* la = hbuf(t & 1, wr);
+        const bf16_t* lb = hbuf(t & 1, 2 + (wc >> 1));
+        if (!(DBG & 2)) { read_b(lb, 0, bf0); read_a(la, 0); if (!(DBG & 32)) read_b(lb, 1, bf1); }
+        if (!(DBG & 1)) { stage_a(0, t + 1); stage_a(1, t + 1); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        G8_BAR();
+        G8_MFMA(0, 0, bf0)
+        G8_MFMA(0, 1, bf1)
+        G8_BAR();
+        if (!(DBG & 2)) read_a(la, 1);
+        if (DBG & 32) read_b(lb, 1, bf1);            // timing experiment (wrong results): 12 reads in either R slot
+        if (!(DBG & 1)) { stage_b(0, t + 2); stage_b(1, t + 2); }
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        G8_BAR();
+        G8_MFMA(1, 1, bf1)
+        G8_MFMA(1, 0, bf0)
+        G8_BAR();
+      }
+    } else
     for (int t = 0; t < nk; ++t) {
       const bf16_t* la = hbuf(t & 1, wr);
       const bf16_t* lb = hbuf(t & 1, 2 + (wc >> 1));
-      if (!(DBG & 2)) { read_b(lb, 0, bf0); read_a(la, 0); read_b(lb, 1, bf1); }
+      if (!(DBG & 2)) { read_b(lb, 0, bf0); read_a(la, 0); if (SCHED == 0) read_b(lb, 1, bf1); }
       if (!(DBG & 1)) stage_a(0, t + 1);
       G8_BAR();
       G8_MFMA(0, 0, bf0)
       G8_BAR();
+      if (SCHED == 1 && !(DBG & 2)) read_b(lb, 1, bf1);
       if (!(DBG & 1)) stage_a(1, t + 1);
+      if (SCHED == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       G8_BAR();
       G8_MFMA(0, 1, bf1)
       G8_BAR();
@@ -471,6 +498,7 @@ __global__ __launch_bounds__(256) void gemm8_reduce_kernel(Gemm8Args p) {
 }
 
 extern int g_gemm8_gm;
+extern int g_gemm8_sched;
 static int g8_gm(int tiles_m) { const int want = g_gemm8_gm > 0 ? g_gemm8_gm : 8; return tiles_m < want ? tiles_m : want; }
 // Called by eagle_gemm_nt_bf16 (gemm_mfma.hip) after its argument checks.
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
@@ -491,7 +519,16 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
   a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = (N + G8_BN - 1) / G8_BN;
   a.gm = g8_gm(a.tiles_m);                          // row tiles per group of the grouped tile order
   a.tn = 0;
-  hipLaunchKernelGGL(gemm_nt8_kernel<true>, dim3(a.tiles_m * a.tiles_n * a.ksplit), dim3(G8_THREADS), 0, stream, a);
+  const dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
+  if (g_gemm8_sched == 0x12) hipLaunchKernelGGL((gemm_nt8_kernel<true, 1, false, false, 2>), grid, dim3(G8_THREADS), 0, stream, a);
+  else if (g_gemm8_sched == 0x22) hipLaunchKernelGGL((gemm_nt8_kernel<true, 2, false, false, 2>), grid, dim3(G8_THREADS), 0, stream, a);
+  else if (g_gemm8_sched == 0x32) hipLaunchKernelGGL((gemm_nt8_kernel<true, 3, false, false, 2>), grid, dim3(G8_THREADS), 0, stream, a);
+  else if (g_gemm8_sched == 0x42) hipLaunchKernelGGL((gemm_nt8_kernel<true, 7, false, false, 2>), grid, dim3(G8_THREADS), 0, stream, a);
+  else if (g_gemm8_sched == 0x62) hipLaunchKernelGGL((gemm_nt8_kernel<true, 32, false, false, 2>), grid, dim3(G8_THREADS), 0, stream, a);
+  else if (g_gemm8_sched == 0x52) hipLaunchKernelGGL((gemm_nt8_kernel<true, 64, false, false, 2>), grid, dim3(G8_THREADS), 0, stream, a);
+  else if (g_gemm8_sched == 0) hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, false, false, 0>), grid, dim3(G8_THREADS), 0, stream, a);
+  else if (g_gemm8_sched == 2) hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, false, false, 2>), grid, dim3(G8_THREADS), 0, stream, a);
+  else hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, false, false, 1>), grid, dim3(G8_THREADS), 0, stream, a);
   int rc = eagle_check_launch();
   if (rc || a.ksplit == 1) return rc;
   const int64_t q4 = (int64_t)M * ((N + 3) / 4);
