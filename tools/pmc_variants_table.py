@@ -19,8 +19,9 @@ for d in sys.argv[1:]:
             for v in range(5):
                 rows[v][c] += gem[3 * v:3 * v + 3]
             rows[5][c] += red
-names = ["RT1 rot nt (default)", "RT2 rot nt", "RT1 norot nt", "RT2 norot nt (r01)", "RT1 rot default-policy", "torch sum 262 MB"]
+            rows[6][c] += gem[15:18]          # the packed image (dispatched last)
+names = ["RT1 rot nt (default)", "RT2 rot nt", "RT1 norot nt", "RT2 norot nt (r01)", "RT1 rot default-policy", "torch sum 262 MB", "packed image nt (shipped)"]
 cs = sorted({c for v in rows.values() for c in v})
 print("%-26s" % "variant" + "".join("%24s" % c for c in cs))
-for v in range(6):
+for v in range(7):
     print("%-26s" % names[v] + "".join("%24.1f" % (sum(rows[v][c]) / max(1, len(rows[v][c]))) for c in cs))
