@@ -278,8 +278,10 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
                           void* workspace, hipStream_t stream);
 static int g_gemm8_mode = 2;    // 0: never, 1: whenever legal, 2: by shape (default); eagle_debug_set_gemm8
 int g_gemm8_sched = 2;          // diagnostics: main-loop schedule of the 256x256 NT kernel (gemm_mfma8.hip); mode 0x20000 | sched
+int g_gemm8_nt = 0;             // diagnostics: non-temporal output stores of the 256x256 kernel, 0 by size, 1 always, 2 never; mode 0x30000 | v
 int g_gemm8_gm = 0;             // diagnostics: row tiles per group of the 256x256 kernel's tile order (0: default 8); mode 0x10000 | gm
 extern "C" void eagle_debug_set_gemm8(int mode) {
+  if (mode >= 0x30000) { g_gemm8_nt = mode & 0xff; return; }
   if (mode >= 0x20000) { g_gemm8_sched = mode & 0xff; return; }
   if (mode >= 0x10000) { g_gemm8_gm = mode & 0xff; return; }
   if (mode >= 0x100) { g_rows_cfg = mode & 0xfff; return; }     // 0x100 | BM<<4... see the header

@@ -54,6 +54,7 @@ struct Gemm8Args {
   int kchunk;          // K tiles per slice
   float* partial;      // [ksplit][M][N] fp32 (split-K only)
   int tn;              // operands stored K-major: A [K, M] (row stride lda), B [K, N] (row stride ldb)
+  int nt_store;        // bf16 output written with non-temporal stores (outputs too large to be re-read from cache)
 };
 
 // Operand staging by buffer_load ... lds: the row/chunk part of every lane's source address never
@@ -388,7 +389,13 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
           v.z = pack2bf(lo_bf(v.z) + lo_bf(rv.z), hi_bf(v.z) + hi_bf(rv.z));
           v.w = pack2bf(lo_bf(v.w) + lo_bf(rv.w), hi_bf(v.w) + hi_bf(rv.w));
         }
-        *reinterpret_cast<uint4*>((bf16_t*)p.C + grow * p.ldc + gcol) = v;
+        if (p.nt_store) {
+          typedef __attribute__((ext_vector_type(4))) unsigned int g8_u32x4;
+          g8_u32x4 w = {v.x, v.y, v.z, v.w};
+          __builtin_nontemporal_store(w, reinterpret_cast<g8_u32x4*>((bf16_t*)p.C + grow * p.ldc + gcol));
+        } else {
+          *reinterpret_cast<uint4*>((bf16_t*)p.C + grow * p.ldc + gcol) = v;
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -499,6 +506,8 @@ __global__ __launch_bounds__(256) void gemm8_reduce_kernel(Gemm8Args p) {
 
 extern int g_gemm8_gm;
 extern int g_gemm8_sched;
+extern int g_gemm8_nt;            // 0: by size (default), 1: always, 2: never
+static int g8_nt_store(int64_t out_bytes) { return g_gemm8_nt == 1 ? 1 : g_gemm8_nt == 2 ? 0 : out_bytes > (256ll << 20); }
 static int g8_gm(int tiles_m) { const int want = g_gemm8_gm > 0 ? g_gemm8_gm : 8; return tiles_m < want ? tiles_m : want; }
 // Called by eagle_gemm_nt_bf16 (gemm_mfma.hip) after its argument checks.
 int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
@@ -519,6 +528,7 @@ int eagle_launch_gemm_nt8(const void* A, int64_t lda, const void* B, int64_t ldb
   a.tiles_m = (M + G8_BM - 1) / G8_BM; a.tiles_n = (N + G8_BN - 1) / G8_BN;
   a.gm = g8_gm(a.tiles_m);                          // row tiles per group of the grouped tile order
   a.tn = 0;
+  a.nt_store = g8_nt_store((int64_t)M * N * (out_f32 ? 4 : 2));
   const dim3 grid(a.tiles_m * a.tiles_n * a.ksplit);
   if (g_gemm8_sched == 0x12) hipLaunchKernelGGL((gemm_nt8_kernel<true, 1, false, false, 2>), grid, dim3(G8_THREADS), 0, stream, a);
   else if (g_gemm8_sched == 0x22) hipLaunchKernelGGL((gemm_nt8_kernel<true, 2, false, false, 2>), grid, dim3(G8_THREADS), 0, stream, a);
@@ -554,6 +564,7 @@ extern "C" int eagle_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int
   a.ksplit = 1; a.kchunk = K / G8_BK; a.partial = nullptr;
   a.gm = g8_gm(a.tiles_m);
   a.tn = 1;
+  a.nt_store = g8_nt_store((int64_t)M * N * (out_f32 ? 4 : 2));
   hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, true, true>), dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
   return eagle_check_launch();
 }
@@ -577,6 +588,7 @@ extern "C" int eagle_gemm_nn_bf16(const void* A, int64_t lda, const void* B, int
   a.ksplit = 1; a.kchunk = K / G8_BK; a.partial = nullptr;
   a.gm = g8_gm(a.tiles_m);
   a.tn = 1;
+  a.nt_store = g8_nt_store((int64_t)M * N * (out_f32 ? 4 : 2));
   hipLaunchKernelGGL((gemm_nt8_kernel<true, 0, false, true>), dim3(a.tiles_m * a.tiles_n), dim3(G8_THREADS), 0, stream, a);
   return eagle_check_launch();
 }

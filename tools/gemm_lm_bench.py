@@ -12,13 +12,13 @@ for M, N, K, name in shapes:
         from eagle_amd.train import lm_dgrad_ksplit
         ks = lm_dgrad_ksplit(M, N, K)
     from eagle_amd._hip import lib
-    gms = [int(x) for x in sys.argv[1:]] or [0, 1, 2]      # main-loop schedules (eagle_debug_set_gemm8(0x20000 | sched))
-    res = {f"ours sched={g}": [] for g in gms}
+    gms = [int(x, 0) for x in sys.argv[1:]] or [0x20000, 0x20001, 0x20002]      # eagle_debug_set_gemm8 words: 0x20000 | schedule, 0x30000 | nt stores (1 on, 2 off)
+    res = {f"ours knob={g:#x}": [] for g in gms}
     res["hipblaslt"] = []
     for rnd in range(4):
         for which in res:
             if which != "hipblaslt":
-                lib().eagle_debug_set_gemm8(0x20000 | int(which.split("=")[1]))
+                lib().eagle_debug_set_gemm8(int(which.split("=")[1], 0))
             fn = (lambda: ops.gemm_nt(A, B, out=C, ksplit=ks)) if which != "hipblaslt" else (lambda: torch.matmul(A, B.t(), out=C))
             for _ in range(2): fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -28,5 +28,6 @@ for M, N, K, name in shapes:
             res[which].append(e0.elapsed_time(e1) / 5)
     for which, v in res.items():
         v.sort()
-        print(f"{name:14s} {M}x{N}x{K} {which:12s}: median {v[len(v)//2]*1e3:8.1f} us = {2*M*N*K/v[len(v)//2]/1e9:7.1f} TFLOP/s   (min {v[0]*1e3:8.1f} us)", flush=True)
+        print(f"{name:14s} {M}x{N}x{K} {which:18s}: median {v[len(v)//2]*1e3:8.1f} us = {2*M*N*K/v[len(v)//2]/1e9:7.1f} TFLOP/s   (min {v[0]*1e3:8.1f} us)", flush=True)
 lib().eagle_debug_set_gemm8(0x20000 | 2)
+lib().eagle_debug_set_gemm8(0x30000)
