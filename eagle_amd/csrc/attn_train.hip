@@ -586,6 +586,51 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(bf16_t* __restrict__ qkv, 
   x[d + half] = f2bf(y1);
 }
 
+// The same rotation, eight pairs per thread: (d .. d+7, d+half .. d+half+7) as 16-byte loads and stores (hd % 16 == 0, ld % 8 == 0,
+// 16-byte aligned bases).  Identical arithmetic per element.
+__global__ __launch_bounds__(256) void rope_qk_vec_kernel(bf16_t* __restrict__ qkv, int64_t ld, const int64_t* __restrict__ pos,
+                                                         const bf16_t* __restrict__ cos_t, const bf16_t* __restrict__ sin_t, int n_pos,
+                                                         int64_t nrows, int L, int heads2, int hd, int inverse) {
+  const int half = hd >> 1, per_head = half >> 3;            // threads per head
+  const int per_row = heads2 * per_head;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nrows * per_row) return;
+  const int64_t row = idx / per_row;
+  const int rem = (int)(idx - row * per_row);
+  const int hh = rem / per_head, d = (rem - hh * per_head) << 3;
+  int64_t ps = pos ? pos[row] : (row % L);
+  ps = ps < 0 ? 0 : (ps >= n_pos ? n_pos - 1 : ps);
+  bf16_t* x = qkv + row * ld + (int64_t)hh * hd + d;
+  const uint4 xa = *reinterpret_cast<const uint4*>(x), xb = *reinterpret_cast<const uint4*>(x + half);
+  const uint4 c0v = *reinterpret_cast<const uint4*>(cos_t + ps * hd + d), c1v = *reinterpret_cast<const uint4*>(cos_t + ps * hd + d + half);
+  const uint4 s0v = *reinterpret_cast<const uint4*>(sin_t + ps * hd + d), s1v = *reinterpret_cast<const uint4*>(sin_t + ps * hd + d + half);
+  const uint32_t* ua = reinterpret_cast<const uint32_t*>(&xa); const uint32_t* ub = reinterpret_cast<const uint32_t*>(&xb);
+  const uint32_t* uc0 = reinterpret_cast<const uint32_t*>(&c0v); const uint32_t* uc1 = reinterpret_cast<const uint32_t*>(&c1v);
+  const uint32_t* us0 = reinterpret_cast<const uint32_t*>(&s0v); const uint32_t* us1 = reinterpret_cast<const uint32_t*>(&s1v);
+  uint32_t oa[4], ob[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float y0[2], y1[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float a = e ? hi_bf(ua[j]) : lo_bf(ua[j]), bb = e ? hi_bf(ub[j]) : lo_bf(ub[j]);
+      const float c0 = e ? hi_bf(uc0[j]) : lo_bf(uc0[j]), c1 = e ? hi_bf(uc1[j]) : lo_bf(uc1[j]);
+      const float s0 = e ? hi_bf(us0[j]) : lo_bf(us0[j]), s1 = e ? hi_bf(us1[j]) : lo_bf(us1[j]);
+      if (!inverse) {
+        y0[e] = rbf(a * c0) + rbf(-bb * s0);
+        y1[e] = rbf(bb * c1) + rbf(a * s1);
+      } else {
+        y0[e] = a * c0 + bb * s1;
+        y1[e] = bb * c1 - a * s0;
+      }
+    }
+    oa[j] = pack2bf(y0[0], y0[1]);
+    ob[j] = pack2bf(y1[0], y1[1]);
+  }
+  *reinterpret_cast<uint4*>(x) = make_uint4(oa[0], oa[1], oa[2], oa[3]);
+  *reinterpret_cast<uint4*>(x + half) = make_uint4(ob[0], ob[1], ob[2], ob[3]);
+}
+
 static int at_check(const void* qkv, int64_t ld, int B, int L, int H, int hd) {
   if (!qkv) return EAGLE_ERR_ARG;
   if (B < 1 || L < 1 || H < 1 || hd != AT_HD || (ld & 7) || ld < 3 * H * hd) return EAGLE_ERR_SHAPE;
@@ -597,6 +642,14 @@ extern "C" int eagle_rope_qk_bf16(void* qkv, int64_t ld, const int64_t* position
                                   hipStream_t stream) {
   if (!qkv || !cos_table || !sin_table) return EAGLE_ERR_ARG;
   if (nrows < 1 || n_heads_qk < 1 || hd < 2 || (hd & 1) || L < 1 || (!position_ids && n_pos < L)) return EAGLE_ERR_SHAPE;
+  const bool vec = (hd % 16 == 0) && (ld % 8 == 0) &&
+                   (((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(cos_table) | reinterpret_cast<uintptr_t>(sin_table)) & 15) == 0);
+  if (vec) {
+    const int64_t threads = nrows * n_heads_qk * (hd / 16);
+    hipLaunchKernelGGL(rope_qk_vec_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (bf16_t*)qkv, ld, position_ids,
+                       (const bf16_t*)cos_table, (const bf16_t*)sin_table, n_pos, nrows, L, n_heads_qk, hd, inverse);
+    return eagle_check_launch();
+  }
   const int64_t total = nrows * n_heads_qk * (hd / 2);
   hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (bf16_t*)qkv, ld, position_ids,
                      (const bf16_t*)cos_table, (const bf16_t*)sin_table, n_pos, nrows, L, n_heads_qk, hd, inverse);

@@ -911,9 +911,10 @@ def test_attn_train_fwd_bwd(B, L, H):
         close(dqkv[:, sl], dref[:, sl], rtol=2e-2, what=name)
 
 
-def test_rope_qk_forward_and_inverse():
+@pytest.mark.parametrize("hd", [128, 24])      # 16-byte vector kernel / scalar kernel (hd % 16 != 0)
+def test_rope_qk_forward_and_inverse(hd):
     from eagle_amd import ops
-    H, hd, L, B = 3, 128, 37, 2
+    H, L, B = 3, 37, 2
     g = torch.Generator().manual_seed(8)
     qkv = torch.randn(B * L, 3 * H * hd, generator=g).to(BF)
     cos, sin = dm.rope_tables(hd, 64)
