@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=6)
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--resident-mb", type=float, default=None, help="Infinity-Cache residency budget of the draft head's matrices (default: the drafter's)")
+    ap.add_argument("--head-two-step", action="store_true", help="A/B: lm_head logits + two-stage top-k instead of the candidate epilogue (1-16 rows)")
     ap.add_argument("--plant", type=float, default=0.8, help="probability that the synthetic verifier agrees with a drafted child")
     return ap.parse_args()
 
@@ -200,32 +201,46 @@ def run_cycles(drafter, ver, prompt_hidden, prompt_tokens, n_cycles, record, pla
 
 
 def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
-    """Dominant kernel: gemm_skinny_keepx_kernel<1,0,4> = the lm_head weight stream (one launch per
-    draft-tree step).  Measured IN the cycle, not back to back: `cycles` eager draft/verify cycles
-    with a HIP event pair (on the launch stream = torch's current stream) around every lm_head
-    launch, so each launch starts behind the down-projection kernel as it does in the timed region
-    (a back-to-back loop of the same launch runs ~13 % faster because consecutive launches overlap
-    their ramp and drain).  Algorithmic bytes per launch = V*D*2 (weights) + M*D*2 (x) + M*V*2
-    (logits), M = the step's row count; achieved = sum(bytes) / sum(durations).
-    `traffic`: HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape
-    (profiles/r02_lm_head_pmc.json, collected with tools/gpu_profile.sh), else null."""
+    """Dominant kernel: gemm_skinny_keepx_kernel<1,0,4,...> = the lm_head weight stream over the packed image (one launch per
+    draft-tree step; since round 3 with the top-k candidate epilogue, so no logits are written).  Measured IN the cycle,
+    not back to back: `cycles` eager draft/verify cycles with a HIP event pair (on the launch stream = torch's current
+    stream) around every lm_head launch, so each launch starts behind the down-projection kernel as it does in the
+    timed region (a back-to-back loop of the same launch runs faster because consecutive launches overlap their ramp and
+    drain).  For the probe the entry point's second launch (the candidate merge) is switched off
+    (eagle_debug_set_rows bit 11), so the event pair brackets the weight-stream launch alone; the tables then keep the
+    previous cycles' ids, which changes no kernel's duration.  Algorithmic bytes per launch = V*D*2 (weights) + M*D*2 (x)
+    + M*blocks*k*8 (candidate records), M = the step's row count; achieved = sum(bytes) / sum(durations).
+    `traffic`: HBM bytes per launch from rocprofv3 PMC passes of the same kernel and shape (profiles/r03_lm_head_pmc.json,
+    collected with tools/gpu_profile_r03.sh), else null."""
     from eagle_amd import ops
+    from eagle_amd._hip import lib
     W = drafter.lm_head_pk                                # what the drafter hands to the weight-stream GEMM (packed image)
     V, D = drafter.lm_head.shape
-    real = ops.linear_skinny
+    real_lin, real_tk = ops.linear_skinny, ops.lm_head_topk_into_table
     marks = []
 
-    def probed(x, Wt, *a, **kw):
-        if Wt is not W:
-            return real(x, Wt, *a, **kw)
+    def timed(fn, rows, *a, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = real(x, Wt, *a, **kw)
+        out = fn(*a, **kw)
         e1.record()
-        marks.append((e0, e1, out.shape[0]))
+        marks.append((e0, e1, rows))
         return out
 
-    ops.linear_skinny = probed
+    def probed_lin(x, Wt, *a, **kw):
+        if Wt is not W:
+            return real_lin(x, Wt, *a, **kw)
+        return timed(real_lin, kw.get("M") or x.shape[0], x, Wt, *a, **kw)
+
+    def probed_tk(x, Wt, *a, **kw):
+        if Wt is not W:
+            return real_tk(x, Wt, *a, **kw)
+        return timed(real_tk, kw.get("M") or x.shape[0], x, Wt, *a, **kw)
+
+    fused = getattr(drafter, "_head_ws", None) is not None and drafter.head_topk_fused
+    ops.linear_skinny, ops.lm_head_topk_into_table = probed_lin, probed_tk
+    if fused:
+        lib().eagle_debug_set_rows(0, 0, 1 << 11)        # candidate GEMM only
     try:
         for c in range(cycles):
             tl, th = ver.logits[c % ver.logits.shape[0]][None], ver.hidden[c % ver.hidden.shape[0]][None]
@@ -234,10 +249,13 @@ def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
             drafter.draft(acc_h, drafter.next_ids)
         torch.cuda.synchronize()
     finally:
-        ops.linear_skinny = real
+        ops.linear_skinny, ops.lm_head_topk_into_table = real_lin, real_tk
+        lib().eagle_debug_set_rows(0, 0, 0)
     marks = marks[len(marks) // 6:]                      # first cycles: warm-up
     sec = sum(e0.elapsed_time(e1) for e0, e1, _ in marks) / 1e3
-    nbytes = sum(V * D * 2 + m * D * 2 + m * V * 2 for _, _, m in marks)
+    blocks = ops.query("eagle_lm_head_topk_rows_workspace_bytes", 1, V, D, drafter.k) // (drafter.k * 8) if fused else 0
+    out_bytes = (lambda m: m * blocks * drafter.k * 8) if fused else (lambda m: m * V * 2)
+    nbytes = sum(V * D * 2 + m * D * 2 + out_bytes(m) for _, _, m in marks)
     traffic = None
     for name in ("r03_lm_head_pmc.json", "r02_lm_head_pmc.json", "r01_lm_head_pmc.json"):      # newest PMC pass of this kernel and shape
         pj = os.path.join(ROOT, "profiles", name)
@@ -246,7 +264,8 @@ def roofline_lm_head(drafter, ver, tgt_kv, root, prev_len, cycles=24):
                 traffic = json.load(f).get("traffic_bytes_per_launch")
             break
     n = len(marks)
-    return {"bound": "hbm", "kernel": "gemm_skinny_keepx_kernel<1,0,4> (lm_head weight stream over the packed image, 1-8 rows, in-cycle)",
+    return {"bound": "hbm", "kernel": "gemm_skinny_keepx_kernel<1,0,4,...> (lm_head weight stream over the packed image, 1-8 rows, in-cycle%s)"
+                                      % (", top-k candidate epilogue" if fused else ""),
             "achieved": nbytes / sec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": nbytes / sec / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "bytes_per_launch": nbytes / n, "us_per_launch": sec / n * 1e6, "launches_timed": n,
@@ -586,6 +605,8 @@ def main():
     note(f"world {world}, backend {backend if world > 1 else 'none'}: building the draft head")
     cfg, model, lm_head = make_model(a.config, dev, seed=0)
     drafter = EagleDrafter(model, lm_head, expand=a.expand, batch=1, max_ctx=2048)
+    if a.head_two_step:
+        drafter.head_topk_fused = False
     if a.resident_mb is not None:
         model.set_cache_residency(drafter.lm_head_pk, a.resident_mb)
     n_fw = 1 + len(drafter.tb.steps)

@@ -568,12 +568,14 @@ static int g_rows_rotate = 1;
 static int g_rows_two_launch = 1;
 static int g_rows_narrow = 1;        // 3/4-width column tiles where they fill whole rounds (bit 10 of `stages` clears it)
 static int g_rows_wide = 1;          // gemm_rows_wide_kernel for the many-tile, 81..128-row case (bit 9 of `stages` clears it)
+static int g_head_skip_merge = 0;    // eagle_lm_head_topk_rows_bf16 stops after the candidate GEMM (bit 11 of `stages`: timing of that launch alone)
 extern "C" void eagle_debug_set_rows(int target_wg, int min_steps, int stages) {
   g_rows_target_wg = target_wg > 0 ? target_wg : 0;
   g_rows_min_steps = min_steps > 0 ? min_steps : 4;
   g_rows_two_launch = ((stages >> 8) & 1) ? 0 : 1;
   g_rows_wide = ((stages >> 9) & 1) ? 0 : 1;
   g_rows_narrow = ((stages >> 10) & 1) ? 0 : 1;
+  g_head_skip_merge = (stages >> 11) & 1;
   stages &= 0xff;
   g_rows_stages = stages & 15;
   g_rows_rotate = (stages >> 4) ? (stages >> 4) - 1 : 1;
@@ -743,7 +745,15 @@ static bool gr_topk_plan(int M, int N, int K, int k, RowsPlan& pl) {
   pl = gr_plan(M, N, K, GR_EPI_LINEAR, false);
   return pl.wide && (int64_t)pl.tiles * k <= 256 * 24;
 }
+// 1..16 rows (every tree step of ONE request) over a packed image with K = 4096: the register-resident weight stream of
+// gemm_skinny.hip with the same candidate epilogue (gemm_skinny_keepx_kernel<..., TKP>), [M][blocks][k] records.
+int eagle_skinny_topk_blocks(int M, int N, int K, int k);
+int eagle_topk_merge_candidates_bounded(const void* cand, int ncand, int rows, int k, int64_t* out_idx, void* out_val,
+                                        int group, int64_t group_stride, int index_bound, hipStream_t stream);
+int eagle_launch_skinny_topk(const void* x0, const int64_t* idx0, int64_t ld0, const int64_t* ind0, int ind_n, int64_t idx0_bstride,
+                             const void* Wpacked, const void* bias, int M, int N, int K, int k, void* cand, bool nt, hipStream_t st);
 extern "C" int64_t eagle_lm_head_topk_rows_workspace_bytes(int M, int N, int K, int k) {
+  if (M >= 1 && M <= 16) return (int64_t)M * eagle_skinny_topk_blocks(M, N, K, k) * k * 8;
   RowsPlan pl;
   if (!gr_topk_plan(M, N, K, k, pl)) return 0;
   return (int64_t)pl.mt * 16 * pl.tiles * k * 8;
@@ -754,6 +764,16 @@ extern "C" int eagle_lm_head_topk_rows_bf16(const void* x0, const int64_t* idx0,
                                             int64_t group_stride, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
   if (!x0 || !W || !out_idx || !workspace) return EAGLE_ERR_ARG;
   if (ind0 && (!idx0 || ind_n < 1)) return EAGLE_ERR_ARG;
+  if (M >= 1 && M <= 16) {                               // one request's tree step: packed image only
+    const int blocks = eagle_skinny_topk_blocks(M, N, K, k);
+    if (!blocks || ldw != 0) return EAGLE_ERR_SHAPE;
+    if ((ld0 & 7) || !gr_al16(x0) || !gr_al16(W) || (reinterpret_cast<uintptr_t>(workspace) & 7)) return EAGLE_ERR_SHAPE;
+    if (ld0 < K && !idx0 && M > 1) return EAGLE_ERR_SHAPE;
+    if (workspace_bytes < (int64_t)M * blocks * k * 8) return EAGLE_ERR_ARG;
+    int rc = eagle_launch_skinny_topk(x0, idx0, ld0, ind0, ind_n, idx0_bstride, W, bias, M, N, K, k, workspace, true, stream);
+    if (rc || g_head_skip_merge) return rc;
+    return eagle_topk_merge_candidates_bounded(workspace, blocks * k, M, k, out_idx, out_val, group, group_stride, N, stream);
+  }
   RowsPlan pl;
   if (!gr_topk_plan(M, N, K, k, pl)) return EAGLE_ERR_SHAPE;
   const bool packed = ldw == 0;                          // ldw == 0: W is an eagle_pack_weight_bf16 image
@@ -779,6 +799,6 @@ extern "C" int eagle_lm_head_topk_rows_bf16(const void* x0, const int64_t* idx0,
   } else if (pl.mt == 6) hipLaunchKernelGGL((gemm_rows_wide_kernel<6, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, stream, a);
   else hipLaunchKernelGGL((gemm_rows_wide_kernel<8, true>), dim3(a.tiles), dim3(GW_NW * 64), 0, stream, a);
   int rc = eagle_check_launch();
-  if (rc) return rc;
+  if (rc || g_head_skip_merge) return rc;
   return eagle_topk_merge_candidates(workspace, pl.tiles * k, M, k, out_idx, out_val, group, group_stride, stream);
 }

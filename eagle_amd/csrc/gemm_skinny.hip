@@ -21,6 +21,7 @@
 //     ([N/16][K/32][64 lanes][8 bf16]), so the same registers are filled by whole-line reads; the arithmetic (and therefore
 //     every output bit) is unchanged.
 #include "common.h"
+#include "topk_select.h"
 #include <type_traits>
 
 #define SK_WAVES 8
@@ -40,6 +41,7 @@ struct SkinnyArgs {
   int rot;                                               // keepx: neighbouring blocks walk their K super-steps from staggered starts
   int stage;                                             // keepx: collect a block's outputs in LDS and write them when its stream is done
   int packed;                                            // host-side only: W / W2 are eagle_pack_weight_bf16 images
+  unsigned long long* cand; int topk;                    // keepx<..., TKP>: [M][blocks][topk] candidate records instead of `out`
 };
 
 // Packed image: tile T = rows [16T, 16T+16), k-block f = columns [32f, 32f+32): 512 elements at (T * K/32 + f) * 512, lane
@@ -459,9 +461,16 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_stream_kernel(Skinn
 // MT = 16-row activation tiles whose fragments stay in registers (1: <= 16 rows, every tree step of one request; 2: <= 32
 // rows, a 32-request batch at one row each -- each weight fragment then feeds two MFMAs instead of one).
 #define SK_OST_COLS 640
-template <int RT, int EPI, int NI, bool NT, int S = 2, int MT = 1, bool STAGE = false, bool PK = false>
+// TKP > 0 (lm_head + top-k of 1-16 rows, no logits leave the kernel): the block's outputs become 16-bit monotone keys in LDS
+// ([row][32 * TKP column slots], the slots past the block's columns hold key 0); when its stream is done every 16-lane group
+// selects the p.topk best of one row (topk_select.h) and writes them as candidate records [row][block][topk] in topk.hip's
+// format -- eagle_topk_merge_candidates finishes the job.  Against logits + the two-stage top-k: one launch and one 4 us scan
+// of the logits less per draft step, the same ids and values (same rounding, same order: value, then lowest index).
+#define SK_KSTRIDE(TKP) (64 * (TKP) + 64)               // bytes per key row: 4 rows read side by side fall in 4 different bank quarters
+template <int RT, int EPI, int NI, bool NT, int S = 2, int MT = 1, bool STAGE = false, bool PK = false, int TKP = 0>
 __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(SkinnyArgs p, int rows_per_block) {
   static_assert(NI % S == 0, "S register stages rotate through the NI super-steps of a tile-step");
+  static_assert(TKP == 0 || (EPI == EPI_LINEAR && !STAGE), "the top-k form has the linear epilogue and its own LDS image");
   constexpr int RTW = (EPI == EPI_SILU_MUL) ? RT / 2 : RT;
   constexpr int RPS = RTW * 16;
   __shared__ __attribute__((aligned(16))) float red[2][SK_WAVES][MT * RT][64][4];
@@ -474,8 +483,12 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   // (32 rows: 253 -> 230 us).  The copy is a serial tail of ~1.5 us, so the launcher asks for it from M x N >= 400000 only
   // (the batch-1 lm_head of 32000 columns at 1-8 rows is faster without: 52.7 vs 54.2 us).
   __shared__ __attribute__((aligned(16))) bf16_t ost[STAGE ? MT * 16 : 1][STAGE ? SK_OST_COLS + 8 : 8];
+  __shared__ __attribute__((aligned(16))) unsigned char kimg[TKP ? MT * 16 * SK_KSTRIDE(TKP) : 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
+  if (TKP) {                                           // key 0 everywhere; the first tile-step's barrier orders it before the key stores
+    for (int i = threadIdx.x; i < MT * 16 * SK_KSTRIDE(TKP) / 16; i += SK_WAVES * 64) reinterpret_cast<uint4*>(kimg)[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
   const bool stage_out = STAGE && rows_per_block <= SK_OST_COLS && ((rows_per_block | (int)(p.ldo & 7)) & 7) == 0 &&
                          ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
   const int row_lo = blockIdx.x * rows_per_block;
@@ -621,6 +634,13 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
                 y[r] = v;
               }
             }
+            if constexpr (TKP > 0) {               // keys instead of logits; columns past row_hi keep key 0
+              uint32_t k16[4];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) k16[r] = (nb + r < row_hi) ? tk_mono_bf16(f2bf(y[r])) : 0u;
+              *reinterpret_cast<uint2*>(kimg + m * SK_KSTRIDE(TKP) + 2 * (nb - row_lo)) = make_uint2(k16[0] | (k16[1] << 16), k16[2] | (k16[3] << 16));
+              continue;
+            }
             bf16_t* o = p.out + (int64_t)m * p.ldo + nb;
             if (stage_out) {                       // columns past row_hi are staged too and never copied out
               uint2 v = {pack2bf(y[0], y[1]), pack2bf(y[2], y[3])};
@@ -638,6 +658,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void gemm_skinny_keepx_kernel(Skinny
   };
   for (int ts = 0; ts + 1 < n_ts; ++ts) tile_step(ts, std::false_type{});
   tile_step(n_ts - 1, std::true_type{});
+  if constexpr (TKP > 0) {                             // selection: one 16-lane group per row
+    __syncthreads();
+    const int l16 = threadIdx.x & 15;
+    for (int R = threadIdx.x >> 4; R < min(p.M, MT * 16); R += SK_WAVES * 4)
+      tk_select_group16<TKP>(kimg + R * SK_KSTRIDE(TKP), row_hi - row_lo, (uint32_t)row_lo, p.topk,
+                             p.cand + ((int64_t)R * gridDim.x + blockIdx.x) * p.topk, true, l16);
+    return;
+  }
   if (!stage_out) return;
   __syncthreads();
   const int ncols = row_hi - row_lo, cpr = (ncols + 7) >> 3;        // 16-byte chunks per row
@@ -718,6 +746,44 @@ static int launch_skinny_keepx_(const SkinnyArgs& a, hipStream_t st) {
 template <int RT, int EPI, int MT = 1>
 static int launch_skinny_keepx(const SkinnyArgs& a, hipStream_t st) {
   return a.packed ? launch_skinny_keepx_<RT, EPI, MT, true>(a, st) : launch_skinny_keepx_<RT, EPI, MT, false>(a, st);
+}
+
+// lm_head + top-k of 1..16 rows over a packed image (K = 4096): blocks / columns per block of the launch, 0 if not served
+static int sk_topk_blocks(int M, int N, int K, int k, int* R_out) {
+  if (M < 1 || M > 16 || K != 128 * SK_WAVES * 4 || N < 16 || k < 1 || k > 16) return 0;
+  int grid = sk_num_cus() * g_sk_keepx_bpc;
+  int R = (N + grid - 1) / grid;
+  if (R < 16) R = 16;
+  R = (R + 15) & ~15;
+  grid = (N + R - 1) / R;
+  if (R > 640 || (int64_t)grid * k > 256 * 24 || N < k) return 0;     // the merge takes <= 6144 candidates (a last block with fewer than k columns leaves empty records, which it skips)
+  if (R_out) *R_out = R;
+  return grid;
+}
+int eagle_skinny_topk_blocks(int M, int N, int K, int k) { return sk_topk_blocks(M, N, K, k, nullptr); }
+// Called by eagle_lm_head_topk_rows_bf16 (gemm_rows.hip) for 1..16 rows after its argument checks; cand: [M][blocks][k] records.
+int eagle_launch_skinny_topk(const void* x0, const int64_t* idx0, int64_t ld0, const int64_t* ind0, int ind_n, int64_t idx0_bstride,
+                             const void* Wpacked, const void* bias, int M, int N, int K, int k, void* cand, bool nt, hipStream_t st) {
+  int R = 0;
+  const int grid = sk_topk_blocks(M, N, K, k, &R);
+  if (!grid) return EAGLE_ERR_SHAPE;
+  SkinnyArgs a;
+  a.x0 = (const bf16_t*)x0; a.idx0 = idx0; a.ld0 = ld0; a.K0 = K;
+  a.ind0 = ind0; a.ind_n = ind_n; a.idx0_bstride = idx0_bstride; a.norm_eps = 0.f;
+  a.x1 = nullptr; a.idx1 = nullptr; a.ld1 = 0;
+  a.W = (const bf16_t*)Wpacked; a.W2 = nullptr; a.bias = (const bf16_t*)bias; a.res = nullptr; a.ldr = 0;
+  a.out = nullptr; a.ldo = 0; a.M = M; a.N = N; a.K = K;
+  a.nt = nt; a.rot = g_sk_rot; a.stage = 0; a.packed = 1;
+  a.cand = (unsigned long long*)cand; a.topk = k;
+#define SK_TOPK(TKP_) do {                                                                                                          \
+    if (nt) hipLaunchKernelGGL((gemm_skinny_keepx_kernel<1, EPI_LINEAR, 4, true, 2, 1, false, true, TKP_>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);  \
+    else hipLaunchKernelGGL((gemm_skinny_keepx_kernel<1, EPI_LINEAR, 4, false, 2, 1, false, true, TKP_>), dim3(grid), dim3(SK_WAVES * 64), 0, st, a, R);   \
+  } while (0)
+  if (R <= 128) SK_TOPK(4);
+  else if (R <= 256) SK_TOPK(8);
+  else SK_TOPK(20);
+#undef SK_TOPK
+  return eagle_check_launch();
 }
 
 template <int RT, int EPI, bool PK>
@@ -821,6 +887,7 @@ extern "C" int eagle_gemm_skinny_bf16(const void* x0, const int64_t* idx0, int64
     a.res = res ? (const bf16_t*)res + (int64_t)m0 * ldr : nullptr; a.ldr = ldr;
     a.out = (bf16_t*)out + (int64_t)m0 * ldo; a.ldo = ldo;
     a.M = mc; a.N = N; a.K = K; a.nt = !keep_resident; a.rot = g_sk_rot; a.packed = packed ? 1 : 0;
+    a.cand = nullptr; a.topk = 0;
     a.stage = (int64_t)mc * N >= 400000 ? 1 : 0;
     int rc;
     const int var = skinny_variant();   // 3 = per-shape choice (measured); 0/1/2 force one kernel family

@@ -402,6 +402,118 @@ __global__ __launch_bounds__(TK_FUSED_WAVES * 64) void topk_fused_bf16_kernel(co
   }
 }
 
+// ---- the merge alone on 16 waves: rows x ncand candidate records (<= 6144) -> k best per row ----
+// For producers that leave many short candidate lists (the lm_head epilogue of the one-request tree steps: 250 workgroups x k
+// records per row).  topk_stage2_kernel holds CM = 16-24 records per thread on 4 waves and rescans them every round it wins;
+// here a thread holds at most CW (2500 records: 3), every wave selects its k best, wave 0 merges the 16 x k survivors --
+// the structure of topk_fused_bf16_kernel's second half.  Same total order (record value = key << 48 | ~index).
+// K32 (every candidate index < 65536): both selections run on 32-bit keys (16-bit value | 0xffff - index), one DPP reduction per round.
+template <int CW, bool K32>
+__global__ __launch_bounds__(TK_FUSED_WAVES * 64) void topk_merge_wide_kernel(const unsigned long long* __restrict__ cand, int ncand, int k,
+                                                                            int64_t* __restrict__ out_idx, bf16_t* __restrict__ out_val,
+                                                                            int out_group, int64_t out_gstride) {
+  __shared__ unsigned long long surv[TK_FUSED_WAVES * TK_MAXK];
+  const int row = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  unsigned long long won = 0;
+  if (K32) {
+    uint32_t* surv32 = reinterpret_cast<uint32_t*>(surv);
+    uint32_t key[CW], best = 0;
+#pragma unroll
+    for (int i = 0; i < CW; ++i) {
+      const int c = t + i * (TK_FUSED_WAVES * 64);
+      const unsigned long long v = c < ncand ? cand[(int64_t)row * ncand + c] : 0ull;
+      key[i] = v ? ((uint32_t)(v >> 32) | ((uint32_t)v & 0xffffu)) : 0u;
+      best = key[i] > best ? key[i] : best;
+    }
+    for (int r = 0; r < k; ++r) {
+      const uint32_t bm = wave_umax(best);
+      if (lane == 0) surv32[wave * TK_MAXK + r] = bm;
+      if (bm != 0 && best == bm) {
+        best = 0;
+#pragma unroll
+        for (int i = 0; i < CW; ++i) {
+          if (key[i] == bm) key[i] = 0;
+          best = key[i] > best ? key[i] : best;
+        }
+      }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    uint32_t key2[4], best2 = 0;                                     // 16 x k <= 256 survivors: four per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = lane + 64 * i;
+      key2[i] = c < TK_FUSED_WAVES * k ? surv32[(c / k) * TK_MAXK + (c % k)] : 0u;
+      best2 = key2[i] > best2 ? key2[i] : best2;
+    }
+    for (int r = 0; r < k; ++r) {
+      const uint32_t bm = wave_umax(best2);
+      if (lane == r) won = bm ? (((unsigned long long)(bm & 0xffff0000u) << 32) | 0xffff0000ull | (bm & 0xffffu)) : 0ull;
+      if (bm != 0 && best2 == bm) {
+        best2 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (key2[i] == bm) key2[i] = 0;
+          best2 = key2[i] > best2 ? key2[i] : best2;
+        }
+      }
+    }
+  } else {
+  unsigned long long key[CW];
+  unsigned long long best = 0;
+#pragma unroll
+  for (int i = 0; i < CW; ++i) {
+    const int c = t + i * (TK_FUSED_WAVES * 64);
+    key[i] = c < ncand ? cand[(int64_t)row * ncand + c] : 0ull;
+    best = key[i] > best ? key[i] : best;
+  }
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long bm = wave_umax64(best);
+    if (lane == 0) surv[wave * TK_MAXK + r] = bm;
+    if (bm != 0 && best == bm) {
+      best = 0;
+#pragma unroll
+      for (int i = 0; i < CW; ++i) {
+        if (key[i] == bm) key[i] = 0;
+        best = key[i] > best ? key[i] : best;
+      }
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  unsigned long long key2[4];                                        // 16 x k <= 256 survivors: four per lane
+  unsigned long long best2 = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    key2[i] = c < TK_FUSED_WAVES * k ? surv[(c / k) * TK_MAXK + (c % k)] : 0ull;
+    best2 = key2[i] > best2 ? key2[i] : best2;
+  }
+  for (int r = 0; r < k; ++r) {
+    const unsigned long long bm = wave_umax64(best2);
+    if (lane == r) won = bm;
+    if (bm != 0 && best2 == bm) {
+      best2 = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (key2[i] == bm) key2[i] = 0;
+        best2 = key2[i] > best2 ? key2[i] : best2;
+      }
+    }
+  }
+  }
+  if (lane < k) {
+    const int64_t idx = won ? (int64_t)(0xffffffffu - (uint32_t)(won & 0xffffffffu)) : -1;
+    const int64_t opos = out_group ? (int64_t)(row / out_group) * out_gstride + (int64_t)(row % out_group) * k : (int64_t)row * k;
+    out_idx[opos + lane] = idx;
+    if (out_val) {                                                   // the value back from the record's 16-bit key (-0 comes back as +0)
+      const uint32_t k16 = (uint32_t)(won >> 48);
+      const uint32_t b = k16 == 0xffffu ? 0x7fc0u : (k16 & 0x8000u) ? (k16 & 0x7fffu) : (~k16 & 0xffffu);
+      out_val[opos + lane] = idx >= 0 ? (bf16_t)b : (bf16_t)0;
+    }
+  }
+}
+
 // k = 1 over many long rows (the verifier's argmax at every tree node of a request batch: 832 rows x 151936 logits): one
 // workgroup per row reads the row once and writes the index -- no candidate buffer and no second launch (the two-launch
 // form spends 126k one-kilobyte waves on it: 62 + 4.7 us at 4.1 TB/s).  Same order as everywhere: the monotone 16-bit key,
@@ -504,7 +616,8 @@ __global__ __launch_bounds__(TK_AM_THREADS) void argmax_rows_bf16_kernel(const b
 }
 
 static int g_topk_two_stage = 0;     // diagnostics (tests): 1 = always the two-launch form, 2 = the one-launch form wherever legal
-extern "C" void eagle_debug_set_topk(int two_stage) { g_topk_two_stage = two_stage; }
+static int g_tk_merge_narrow = 0;    // bit 2 of the same word: eagle_topk_merge_candidates always on the four-wave kernel
+extern "C" void eagle_debug_set_topk(int two_stage) { g_topk_two_stage = two_stage & 3; g_tk_merge_narrow = (two_stage >> 2) & 1; }
 
 extern "C" int64_t eagle_topk_workspace_bytes(int rows, int V, int k) {
   const int64_t nwc = (V + TK_WCHUNK - 1) / TK_WCHUNK;
@@ -563,19 +676,39 @@ static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int 
 // Stage 2 alone: rows x ncand candidate records (value key << 48 | 0xffffffff - index; 0 = empty) -> the k best of every row,
 // ids and bf16 values (rebuilt from the keys).  ncand <= 6144.  The records come from eagle_lm_head_topk_rows_bf16's GEMM
 // epilogue (or from any producer that keeps the record order: value first, then the lowest index).
-extern "C" int eagle_topk_merge_candidates(const void* cand, int ncand, int rows, int k, int64_t* out_idx, void* out_val,
-                                           int group, int64_t group_stride, hipStream_t stream) {
+// index_bound: every candidate index is below it (0 = unknown); below 65536 the 16-wave form merges 32-bit keys
+int eagle_topk_merge_candidates_bounded(const void* cand, int ncand, int rows, int k, int64_t* out_idx, void* out_val,
+                                        int group, int64_t group_stride, int index_bound, hipStream_t stream) {
   if (!cand || !out_idx) return EAGLE_ERR_ARG;
   if (rows < 1 || ncand < 1 || ncand > TK_THREADS * 24 || k < 1 || k > TK_MAXK) return EAGLE_ERR_SHAPE;
   if (group < 0 || (group > 0 && (rows % group || group_stride < (int64_t)group * k))) return EAGLE_ERR_SHAPE;
 #define TK_MERGE(CMV) hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false, false, CMV>), dim3(rows), dim3(TK_THREADS), 0, stream,      \
     (const unsigned long long*)cand, ncand, k, (const bf16_t*)nullptr, (int64_t)0, out_idx, (bf16_t*)out_val, (const int64_t*)nullptr, \
     (int64_t)0, (const float2*)nullptr, 0, (float*)nullptr, group, group_stride)
-  if (ncand <= TK_THREADS * 8) TK_MERGE(8);
+  // few rows of many records (one request's tree step): the 16-wave form; many rows (a request batch) keep four waves per row
+#define TK_MERGE_WIDE(CWV) do {                                                                                                  \
+    if (index_bound > 0 && index_bound <= 65536)                                                                                 \
+      hipLaunchKernelGGL((topk_merge_wide_kernel<CWV, true>), dim3(rows), dim3(TK_FUSED_WAVES * 64), 0, stream,                  \
+                         (const unsigned long long*)cand, ncand, k, out_idx, (bf16_t*)out_val, group, group_stride);             \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((topk_merge_wide_kernel<CWV, false>), dim3(rows), dim3(TK_FUSED_WAVES * 64), 0, stream,                 \
+                         (const unsigned long long*)cand, ncand, k, out_idx, (bf16_t*)out_val, group, group_stride);             \
+  } while (0)
+  if (rows <= 16 && ncand > TK_THREADS * 4 && !g_tk_merge_narrow) {
+    if (ncand <= TK_FUSED_WAVES * 64 * 3) TK_MERGE_WIDE(3);
+    else TK_MERGE_WIDE(6);
+  }
+  else if (ncand <= TK_THREADS * 8) TK_MERGE(8);
   else if (ncand <= TK_THREADS * 16) TK_MERGE(16);
   else TK_MERGE(24);
 #undef TK_MERGE
+#undef TK_MERGE_WIDE
   return eagle_check_launch();
+}
+
+extern "C" int eagle_topk_merge_candidates(const void* cand, int ncand, int rows, int k, int64_t* out_idx, void* out_val,
+                                           int group, int64_t group_stride, hipStream_t stream) {
+  return eagle_topk_merge_candidates_bounded(cand, ncand, rows, k, out_idx, out_val, group, group_stride, 0, stream);
 }
 
 // dtype: 0 = bf16 logits, 1 = fp32 logits

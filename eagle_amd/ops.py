@@ -547,7 +547,7 @@ def topk_into_table(logits: torch.Tensor, k: int, table_idx: torch.Tensor, table
 
 
 def lm_head_topk_rows_ok(M: int, N: int, K: int, k: int) -> bool:
-    """True when lm_head_topk_into_table serves the shape (81..128 rows against a tall head)."""
+    """True when lm_head_topk_into_table serves the shape (81..128 rows against a tall head; 1..16 rows with K = 4096, packed W)."""
     return query("eagle_lm_head_topk_rows_workspace_bytes", M, N, K, k) > 0
 
 
@@ -555,9 +555,12 @@ _head_ws_cache = {}
 
 
 def lm_head_topk_into_table(x: torch.Tensor, W: torch.Tensor, k: int, table_idx: torch.Tensor, table_val: torch.Tensor,
-                            row0: int, n: int, idx0: Optional[torch.Tensor] = None, M: Optional[int] = None) -> None:
+                            row0: int, n: int, idx0: Optional[torch.Tensor] = None, M: Optional[int] = None,
+                            workspace: Optional[torch.Tensor] = None) -> None:
     """top-k(x[idx0] @ W^T) of M = B*n rows written into table[:, row0:row0+n, :] of the [B, R, k] tables, without the logits
-    (eagle_lm_head_topk_rows_bf16: candidates out of the GEMM's epilogue + the final merge).  W row-major or a PackedWeight."""
+    (eagle_lm_head_topk_rows_bf16: candidates out of the GEMM's epilogue + the final merge).  W row-major or a PackedWeight;
+    1..16 rows (one request's tree step) are served for a PackedWeight with K = 4096 only.  workspace: uint8 buffer of at least
+    eagle_lm_head_topk_rows_workspace_bytes (a caller that replays HIP graphs owns it); None: a per-stream cache."""
     _chk(x, "x")
     packed = isinstance(W, PackedWeight)
     if not packed:
@@ -576,11 +579,18 @@ def lm_head_topk_into_table(x: torch.Tensor, W: torch.Tensor, k: int, table_idx:
     need = query("eagle_lm_head_topk_rows_workspace_bytes", M, N, K, k)
     if need <= 0:
         raise ValueError("lm_head_topk_into_table: shape not served (see lm_head_topk_rows_ok)")
-    key = (x.device, torch.cuda.current_stream().cuda_stream)
-    ws = _head_ws_cache.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        _head_ws_cache[key] = ws
+    if M <= 16 and not packed:
+        raise ValueError("lm_head_topk_into_table: 1..16 rows need a PackedWeight")
+    if workspace is not None:
+        if workspace.dtype != torch.uint8 or not workspace.is_contiguous() or workspace.numel() < need or workspace.device != x.device:
+            raise ValueError("lm_head_topk_into_table: workspace too small or of the wrong kind")
+        ws = workspace
+    else:
+        key = (x.device, torch.cuda.current_stream().cuda_stream)
+        ws = _head_ws_cache.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            _head_ws_cache[key] = ws
     call("eagle_lm_head_topk_rows_bf16", ptr(x), ptr(idx0), x.stride(0), None, 0, 0, ptr(W.data if packed else W), (0 if packed else K), None, M, N, K, k,
          table_idx.data_ptr() + row0 * k * 8, table_val.data_ptr() + row0 * k * 2, n, R * k, ptr(ws), ws.numel(), stream())
 

@@ -59,7 +59,7 @@ class EagleDrafter:
         self.cap = (max_ctx + self.W + self.n_fwd + 255) // 256 * 256
         self.dev, self.D = dev, model.config.hidden_size
         self.wide_head_rows = 32      # lm_head row blocks from this many rows on take the MFMA GEMM (one weight pass)
-        self.head_topk_fused = True   # 81-128 rows: lm_head + top-k without the logits (eagle_lm_head_topk_rows_bf16)
+        self.head_topk_fused = True   # 81-128 rows, and 1-16 rows of one request: lm_head + top-k without the logits (eagle_lm_head_topk_rows_bf16)
         self.rows_head_max = 128      # ... and up to this many the row-batch weight stream (eagle_gemm_rows_bf16; 81..128 rows: its up-to-384-column form, 292 vs 345 us cold)
         # static bound on stable_len + tree rows handed to the attention launcher (grid size); a caller
         # that knows a tighter bound for the coming cycles may lower it (must stay >= the true length)
@@ -77,6 +77,9 @@ class EagleDrafter:
         self._rowbase = torch.arange(B, dtype=torch.int64, device=dev) * self.W
         rows_max = B * max(self.W, self.tb.n_nodes, 16)
         self._ws = torch.empty(ops.query("eagle_topk_workspace_bytes", rows_max, V, topk), dtype=torch.uint8, device=dev)
+        # candidate records of the one-request tree steps (1-16 rows): owned here, the cycle is replayed as a HIP graph
+        need = ops.query("eagle_lm_head_topk_rows_workspace_bytes", 16, V, self.D, topk) if B == 1 else 0
+        self._head_ws = torch.empty(need, dtype=torch.uint8, device=dev) if need > 0 else None
         ar_b = torch.arange(B, dtype=torch.int64, device=dev)[:, None]
         self._hid_idx, prev_n = [], 1
         for s in self.tb.steps:                               # static batch-major parent-row gathers
@@ -104,6 +107,11 @@ class EagleDrafter:
     # -------------------------------------------------------------- draft side
     def _head_topk(self, x: torch.Tensor, idx: Optional[torch.Tensor], rows: int, row0: int, n: int):
         """top-k(lm_head(x[idx])) -> flat rows [row0, row0+n) of every request."""
+        if self.B == 1 and self.head_topk_fused and rows <= 16 and self._head_ws is not None and isinstance(self.lm_head_pk, ops.PackedWeight):
+            # one request's tree step: the register-resident weight stream leaves k candidates per (row, block), no logits
+            ops.lm_head_topk_into_table(x, self.lm_head_pk, self.k, self.flat_ids, self.flat_vals, row0, n, idx0=idx, M=rows,
+                                        workspace=self._head_ws)
+            return
         if 16 < rows <= 32 and self.D == 4096 and self.lm_head.shape[0] >= 8192:
             # 17-32 rows (a 32-request batch at one row each): both 16-row tiles of x stay in registers of the weight-stream
             # kernel, which reads 2 KB of every weight row per block step (in-cycle 151936 x 4096: see DESIGN.md section 10)

@@ -198,7 +198,9 @@ int eagle_topk_vocab_grouped(const void* logits, int64_t ld, int dtype, int rows
  * half of `torch.topk(logits, k)` for producers that never materialise the logits. */
 int eagle_topk_merge_candidates(const void* cand, int ncand, int rows, int k, int64_t* out_idx, void* out_val,
                                 int group, int64_t group_stride, eagle_stream_t stream);
-/* lm_head + top-k of a tree step of 81..128 rows over a tall head (N >= 32768) without the logits -- replaces
+/* lm_head + top-k of a tree step without the logits, for 81..128 rows of a request batch over a tall head (N >= 32768) and for
+ * 1..16 rows (every tree step of ONE request; K = 4096 and a packed image only: the register-resident weight stream of
+ * eagle_gemm_skinny_bf16 with the same candidate epilogue, one record set per (row, workgroup)) -- replaces
  * `last_headout = lm_head(h)` followed by `torch.topk(last_headout, k)` of the expansion loop (SURVEY.md a11 + a20) for a
  * request batch: the weight-stream GEMM (the 8-wave form of eagle_gemm_rows_bf16: x rows gathered through idx0 / ind0 as there,
  * no second operand) rounds its outputs to bf16 and leaves k candidate records per (row, column tile) in `workspace`
@@ -416,7 +418,8 @@ void eagle_debug_set_skinny_variant(int variant, int blocks_per_cu, int min_rows
 void eagle_debug_set_attn(int no_head_packing);
 /* eagle_topk_vocab*: 1 = always the two-launch form (candidates per 1024 logits, then the merge); 2 = the one-launch form
  * (a 16-wave workgroup per row, candidates in LDS) for every bf16 call of up to 65536 columns; 0 = default: one launch
- * for k <= 2 (the greedy argmax), two otherwise. */
+ * for k <= 2 (the greedy argmax), two otherwise.  Bit 2 (value 4): eagle_topk_merge_candidates always on its four-wave kernel
+ * (default: up to 16 rows of more than 1024 records take the 16-wave form). */
 void eagle_debug_set_topk(int two_stage);
 /* eagle_ce_partial_bf16 / eagle_ce_smoothl1_bwd_bf16: bit 0 = default-policy logit loads (default: non-temporal), bit 1 = one
  * 16-byte chunk pair per thread in flight (default: four), bit 2 = default-policy dlogits stores (default: non-temporal),
@@ -426,7 +429,8 @@ void eagle_debug_set_loss(int variant);
  * super-steps per slice (default 4); stages: bits 0-3 = 2 / 3 / 4 weight register stages (0 = default 3), bits 4-7 =
  * 1 + K-walk stagger of neighbouring column tiles (0 = default stagger 1), bit 8 = sum the partial sums inside the launch (last workgroup of a tile to arrive) instead of in a second launch,
  * bit 9 = keep the many-tile 81..128-row case (a 128-row lm_head) on 128-column tiles instead of the up-to-384-column form,
- * bit 10 = full-width column tiles only (no 3/4-width tiles chosen by the round count). */
+ * bit 10 = full-width column tiles only (no 3/4-width tiles chosen by the round count),
+ * bit 11 = eagle_lm_head_topk_rows_bf16 stops after its candidate GEMM (no merge launch, tables not written: for timing that launch alone). */
 void eagle_debug_set_rows(int target_wg, int min_steps, int stages);
 
 #ifdef __cplusplus

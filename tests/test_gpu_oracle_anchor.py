@@ -171,22 +171,24 @@ def test_batch32_forward_prefill_and_tree_steps_against_the_oracle(HK):
 
 
 # ------------------------------------------------------------------ fused lm_head + top-k (no logits)
-@pytest.mark.parametrize("B,n,N,K", [(32, 4, 151936, 4096), (25, 5, 33000, 384), (128, 1, 40008, 128)])
+@pytest.mark.parametrize("B,n,N,K", [(32, 4, 151936, 4096), (25, 5, 33000, 384), (128, 1, 40008, 128),
+                                     (1, 4, 32000, 4096), (1, 1, 32000, 4096), (1, 16, 151936, 4096), (1, 3, 4100, 4096)])
 def test_fused_lm_head_topk_against_the_stable_sort_oracle(B, n, N, K):
     """eagle_lm_head_topk_rows_bf16 against oracle.tree.stable_topk of the fp32 product rounded to bf16 (what the reference's
     bf16 nn.Linear + torch.topk see, with the oracle's stated tie-break).  The kernel's fp32 accumulation order differs from
     torch's, so a logit can land one bf16 step away: values must agree within one ulp, every (id, value) pair the kernel
-    returns must be that id's logit, and ids must be EQUAL at every rank whose fp32 gaps to both neighbours exceed two ulps."""
+    returns must be that id's logit, and ids must be EQUAL at every rank whose fp32 gaps to both neighbours exceed two ulps.
+    B = 1 (one request's tree step, 1..16 rows): the register-resident weight stream over the packed image (batch-1 cycle)."""
     from eagle_amd import ops
     d = dev()
     g = torch.Generator().manual_seed(B * n + N + 1)
-    M, k, R = B * n, 10, 7
+    M, k, R = B * n, 10, 2 + n + 3
     x = torch.randn(M, K, generator=g).to(BF).to(d)
     W = (torch.randn(N, K, generator=g) / K ** 0.5).to(BF).to(d)
     assert ops.lm_head_topk_rows_ok(M, N, K, k)
     ti = torch.full((B, R, k), -7, dtype=torch.int64, device=d)
     tv = torch.zeros((B, R, k), dtype=BF, device=d)
-    ops.lm_head_topk_into_table(x, W, k, ti, tv, 2, n, M=M)
+    ops.lm_head_topk_into_table(x, ops.pack_weight(W) if M <= 16 else W, k, ti, tv, 2, n, M=M)
     assert int((ti[:, :2] != -7).sum()) == 0 and int((ti[:, 2 + n:] != -7).sum()) == 0, "rows outside [row0, row0+n) touched"
     ids = ti[:, 2:2 + n].reshape(M, k).cpu()
     vals = tv[:, 2:2 + n].reshape(M, k).cpu()
@@ -202,14 +204,14 @@ def test_fused_lm_head_topk_against_the_stable_sort_oracle(B, n, N, K):
     gap_dn = top32[:, :k] - top32[:, 1:k + 1]
     gap_up = torch.cat([torch.full((M, 1), float("inf")), gap_dn[:, :-1]], dim=1)
     untied = (gap_dn > 2 * ulp) & (gap_up > 2 * ulp)
-    assert float(untied.float().mean()) > 0.25, "the check would be vacuous"
+    assert float(untied.float().mean()) > (0.25 if M >= 64 else 0.1), "the check would be vacuous"     # a handful of rows: fewer samples
     assert torch.equal(ids[untied], s32.indices[:, :k][untied]), "ids differ at ranks the oracle's logits separate by > 2 ulp"
     # the kernel's own order: value descending, index ascending
     dv = vals.float()[:, :-1] - vals.float()[:, 1:]
     assert bool((dv >= 0).all()) and bool((ids[:, :-1][dv == 0] < ids[:, 1:][dv == 0]).all())
 
 
-@pytest.mark.parametrize("B,n,N,K", [(32, 4, 151936, 128), (27, 3, 70000, 256)])
+@pytest.mark.parametrize("B,n,N,K", [(32, 4, 151936, 128), (27, 3, 70000, 256), (1, 7, 32000, 4096), (1, 16, 50000, 4096)])
 def test_fused_lm_head_topk_exact_on_integer_logits(B, n, N, K):
     """Operands in {-1, 0, 1}: every product sum is a small integer, exact in fp32 and in bf16 whatever the summation order,
     so the kernel's logits equal the oracle's bit for bit and the vocabulary is full of ties -- ids and values must equal
@@ -219,12 +221,14 @@ def test_fused_lm_head_topk_exact_on_integer_logits(B, n, N, K):
     g = torch.Generator().manual_seed(N + K)
     M, k = B * n, 10
     x = torch.randint(-1, 2, (M, K), generator=g).to(BF)
+    if K > 256:
+        x[:, 256:] = 0                                               # |logit| <= 256: integers bf16 holds exactly
     W = torch.randint(-1, 2, (N, K), generator=g).to(BF)
     x[5] = 0                                                         # all-equal row: ids 0..9
     assert ops.lm_head_topk_rows_ok(M, N, K, k)
     ti = torch.zeros((B, n, k), dtype=torch.int64, device=d)
     tv = torch.zeros((B, n, k), dtype=BF, device=d)
-    ops.lm_head_topk_into_table(x.to(d), W.to(d), k, ti, tv, 0, n, M=M)
+    ops.lm_head_topk_into_table(x.to(d), ops.pack_weight(W.to(d)) if M <= 16 else W.to(d), k, ti, tv, 0, n, M=M)
     logits = (x.float().to(d) @ W.float().to(d).t()).cpu()
     assert float(logits.abs().max()) <= 256 and torch.equal(logits, logits.to(BF).float())
     ov, oi = ot.stable_topk(logits.to(BF), k)

@@ -22,15 +22,17 @@ fetch = per_launch(root + "/pmc_fetch", "FETCH_SIZE")
 write = per_launch(root + "/pmc_write", "WRITE_SIZE")
 # gfx950: FETCH_SIZE counts a 128-B request as 64 B for wide coalesced reads -> x2; WRITE_SIZE exact; KiB
 traffic = (sum(fetch) / len(fetch) * 2 + sum(write) / len(write)) * 1024
-alg = V * D * 2 + ROWS * D * 2 + ROWS * V * 2
+BLOCKS, TOPK = 250, 10
+alg = V * D * 2 + ROWS * D * 2 + ROWS * BLOCKS * TOPK * 8       # weights + x + candidate records (no logits leave the kernel)
 json.dump({
-    "kernel": "gemm_skinny_keepx_kernel<1,0,4,...,packed> (lm_head, %d rows x %d x %d bf16, packed weight image)" % (ROWS, V, D),
+    "kernel": "gemm_skinny_keepx_kernel<1,0,4,...,packed,TKP=4> (lm_head, %d rows x %d x %d bf16, packed weight image, top-k candidate epilogue)" % (ROWS, V, D),
     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 tools/prof_lm_head.py (separate passes)",
     "FETCH_SIZE_KB_per_launch": fetch,
     "WRITE_SIZE_KB_per_launch": write,
     "correction": "gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; unit KiB.  "
-                  "Round 3 (profiles/r03_lm_head_fetch_variants.txt): the rule holds when every request is a whole line, as with the packed image; the row-major "
-                  "fragment shape sends half-line requests that the counter tallies at full size, which read as 8.5 % 'over-fetch' in round 2",
+                  "Round 3 (profiles/r03_lm_head_fetch_variants.txt): FETCH_SIZE = TCC_EA0_RDREQ x 64 B whatever the request size, so x2 is right only when every "
+                  "memory request is a whole line, as with the packed image.  The row-major fragment shape (non-temporal half-line pairs) sends 8.3 % more memory "
+                  "requests than lines -- lines fetched twice or as two halves, these counters cannot tell -- which read as 1.085 x in round 2",
     "traffic_bytes_per_launch": traffic,
     "algorithmic_bytes_per_launch": alg,
     "traffic_over_algorithmic": traffic / alg,
