@@ -476,36 +476,30 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_dkv2_kernel(AttnTrainAr
         f32x4 sc[4][2], dp[4][2];
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) { sc[qt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[qt][1] = sc[qt][0]; dp[qt][0] = sc[qt][0]; dp[qt][1] = sc[qt][0]; }
-        bf16x8 qrr[4][4], orr[4][4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int qt = 0; qt < 4; ++qt) {
-            qrr[s][qt] = a2_row_frag(Qt, 16 * qt + r16, 4 * s + g);
-            orr[s][qt] = a2_row_frag(Ot, 16 * qt + r16, 4 * s + g);
-          }
         f32x4 lser[4], dlr[4];                     // this lane's rows 4g..4g+3 of each 16-query tile
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
           lser[qt] = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
           dlr[qt] = *reinterpret_cast<const f32x4*>(dl_s + 16 * qt + 4 * g);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        // fragments are read one 32-wide k step at a time, right before their MFMAs: holding all four steps of Q and dO (128
+        // registers) beside the 128 accumulators and the K / V fragments spilled (324 B of scratch per lane at the 256-register cap)
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s) {
+          bf16x8 qr[4], orw[4];
 #pragma unroll
           for (int qt = 0; qt < 4; ++qt) {
-            sc[qt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrr[s][qt], kf[0][s], sc[qt][0], 0, 0, 0);   // S[q][key]: rows = queries
-            sc[qt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qrr[s][qt], kf[1][s], sc[qt][1], 0, 0, 0);
-            dp[qt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orr[s][qt], vf[0][s], dp[qt][0], 0, 0, 0);   // dP = dO . V^T
-            dp[qt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orr[s][qt], vf[1][s], dp[qt][1], 0, 0, 0);
+            qr[qt] = a2_row_frag(Qt, 16 * qt + r16, 4 * s + g);
+            orw[qt] = a2_row_frag(Ot, 16 * qt + r16, 4 * s + g);
           }
-        bf16x8 otf[2][8], qtf[2][8];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int dt = 0; dt < 8; ++dt) { otf[ks][dt] = a2_tr_frag(Ot, ks, dt, g, tq, tp); qtf[ks][dt] = a2_tr_frag(Qt, ks, dt, g, tq, tp); }
-        __builtin_amdgcn_sched_barrier(0);
+          for (int qt = 0; qt < 4; ++qt) {
+            sc[qt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[qt], kf[0][s], sc[qt][0], 0, 0, 0);   // S[q][key]: rows = queries
+            sc[qt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[qt], kf[1][s], sc[qt][1], 0, 0, 0);
+            dp[qt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orw[qt], vf[0][s], dp[qt][0], 0, 0, 0);  // dP = dO . V^T
+            dp[qt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orw[qt], vf[1][s], dp[qt][1], 0, 0, 0);
+          }
+        }
         const bool need_mask = (q0 < kw + 31) || (q0 + A2_KB > L);   // tile touches the diagonal / the end
         bf16x8 pf[2][2], dsf[2][2];
 #pragma unroll
@@ -528,10 +522,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_dkv2_kernel(AttnTrainAr
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int dt = 0; dt < 8; ++dt) {
-            dv[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf[ks][dt], pf[0][ks], dv[dt][0], 0, 0, 0);
-            dv[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf[ks][dt], pf[1][ks], dv[dt][1], 0, 0, 0);
-            dk[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[ks][dt], dsf[0][ks], dk[dt][0], 0, 0, 0);
-            dk[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf[ks][dt], dsf[1][ks], dk[dt][1], 0, 0, 0);
+            const bf16x8 otf = a2_tr_frag(Ot, ks, dt, g, tq, tp), qtf = a2_tr_frag(Qt, ks, dt, g, tq, tp);
+            dv[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[0][ks], dv[dt][0], 0, 0, 0);
+            dv[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[1][ks], dv[dt][1], 0, 0, 0);
+            dk[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[0][ks], dk[dt][0], 0, 0, 0);
+            dk[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[1][ks], dk[dt][1], 0, 0, 0);
           }
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
