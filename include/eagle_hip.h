@@ -407,7 +407,12 @@ int eagle_input_embed_concat_bf16(const void* hidden, int64_t ldh_b, int64_t ldh
  * that run every selectable path; process-wide, not for production hosts. ---- */
 /* eagle_gemm_nt_bf16: 0 = always the 128x128 kernel, 1 = the 256x256 kernel wherever legal, 2 = by shape (default);
  * 0x100 | cfg: configuration of the decode-batch row kernels (<= 192 rows, N >= 8192): cfg 0 = by shape, 0x23 / 0x24 /
- * 0x43 / 0x83 / 0x93 = (rows / 16) << 4 | LDS stages (0x93: 128 x 256 tiles on 8 waves), 0xfff = never. */
+ * 0x43 / 0x83 / 0x93 = (rows / 16) << 4 | LDS stages (0x93: 128 x 256 tiles on 8 waves), 0xfff = never;
+ * 0x10000 | gm: row tiles per group of the 256x256 kernel's tile order (0 = default 8);
+ * 0x20000 | s: main-loop schedule of the 256x256 NT kernel, s = 2 four slots per K tile (default), 0 / 1 the eight-slot forms of
+ * rounds 1-2; s = 0x12 / 0x22 / 0x32 / 0x42 / 0x52 / 0x62 are TIMING ABLATIONS of schedule 2 whose outputs are WRONG (no DMA / no LDS
+ * reads / neither / neither and no barriers / no output stores / balanced read slots): tools/gemm_lm_bench.py only;
+ * 0x30000 | v: non-temporal bf16 output stores, v = 0 for outputs above 256 MB (default), 1 always, 2 never. */
 void eagle_debug_set_gemm8(int mode);
 /* eagle_gemm_skinny_bf16 at <= 16 rows: 0 = tile kernel, 1 = streaming kernel, 2 = register-resident-x kernel where
  * K = 4096 (streaming otherwise), 3 = by shape (default); blocks_per_cu / min_rows > 0 override the streaming
