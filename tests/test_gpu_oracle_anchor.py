@@ -351,6 +351,51 @@ def test_real_dims_drafter_cycles_against_the_oracle_loop():
     assert sum(c[1] for c in checked) / len(checked) >= 0.4, f"too few rows had an untied top-1 to check: {checked}"
 
 
+def test_batch1_head_without_logits_equals_the_two_step_head_bit_for_bit():
+    """One request's tree steps: lm_head + top-k out of the weight stream's candidate epilogue (EagleDrafter.head_topk_fused, the
+    default) against the same drafter with lm_head logits + eagle_topk_vocab.  Both round the same fp32 sums to bf16 and order
+    by (value, lowest index), so tables, acceptance and lengths must be EQUAL over whole cycles (real A dims)."""
+    from eagle_amd.speculative import EagleDrafter
+    d = dev()
+    dims = dm.DraftDims()
+    w = dm.init_weights(dims, seed=3)
+    w["fc.weight"] *= 0.4
+    w["layers.0.self_attn.o_proj.weight"] *= 0.5
+    w["layers.0.mlp.down_proj.weight"] *= 0.5
+    g = torch.Generator().manual_seed(6)
+    lm = (torch.randn(dims.vocab, dims.hidden, generator=g) * 0.02).to(BF).to(d)
+    m = _model(dims, w)
+    del w
+    tb = ot.generate_tree_buffers()
+    ctx = 40
+    tokens = torch.randint(0, dims.vocab, (1, ctx + 1), generator=g).to(d)
+    hidden = torch.randn(1, ctx, dims.hidden, generator=g).to(BF).to(d)
+    tgt_logits = [(torch.randn(tb.n_nodes, dims.vocab, generator=g) * 2).to(BF).to(d) for _ in range(3)]
+    tgt_hidden = [torch.randn(1, tb.n_nodes, dims.hidden, generator=g).to(BF).to(d) for _ in range(3)]
+    runs = []
+    for fused in (True, False):
+        dr = EagleDrafter(m, lm, batch=1, max_ctx=256)
+        dr.head_topk_fused = fused
+        assert dr._head_ws is not None, "the fused path would not be taken at these dims"
+        tgt_kv = torch.zeros(2, 1, 2, 128, 16, dtype=BF, device=d)
+        rec = []
+        with torch.no_grad():
+            ids, vals = dr.prefill(hidden, tokens)
+            rec.append((ids.clone(), vals.clone()))
+            prev = torch.tensor([ctx], dtype=torch.int32, device=d)
+            root = tokens[:, -1].clone()
+            for c in range(3):
+                res = dr.verify(root, tgt_logits[c][None], prev)
+                acc_h = dr.compact(prev, tgt_kv, tgt_hidden[c], root_io=root, update_prev_len=True)
+                ids, vals = dr.draft(acc_h, dr.next_ids)
+                rec.append((ids.clone(), vals.clone(), res.clone(), dr.next_ids.clone(), dr.stable_len.clone()))
+            dr.check_errors()
+        runs.append(rec)
+    for a, b in zip(*runs):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 # ------------------------------------------------------------------ the whole g3 fixture on the device
 def test_loss_fixture_every_output_and_the_mixed_precision_case(golden_dir):
     """g3 fixture = outputs of the reference's own loss statements (eagle/train.py:106-123 executed by
