@@ -5,6 +5,7 @@
                         (`pad_token_id = 0`, `padding=True`); here the features are already tokenised
                         ({"input_ids", "loss_mask"} per conversation, e.g. from `apply_chat_template(...,
                         return_assistant_tokens_mask=True)` run offline) and only the padding semantics remain.
+``ChatCollator``        eagle/train.py:242-253 with a tokenizer object: chat template + assistant mask + padding, the reference's call.
 ``make_eagle_batch``    eagle/train.py:256-269 (`_make_eagle_input`) given the verifier's last hidden state: truncation
                         to max_model_len, uniform noise (train.py:272-275) drawn on the device, and the shift kernel
                         (eagle_make_eagle_input_bf16).  Returns the reference's dict keys; the result feeds
@@ -42,6 +43,42 @@ class Collator:
             sl = slice(0, n) if self.padding_side == "right" else slice(L - n, L)
             ids[i, sl] = torch.as_tensor(f["input_ids"], dtype=torch.long)
             mask[i, sl] = torch.as_tensor(f["loss_mask"], dtype=torch.long)
+        return {"input_ids": ids, "loss_mask": mask}
+
+
+class ChatCollator:
+    """eagle/train.py:242-253 WITH the tokenizer: conversations ({"messages": [...]} features) go through the verifier's chat
+    template with the assistant-token mask as the loss mask, padded to the longest of the batch with id 0.
+
+    The tokenizer is the caller's: ``ChatCollator.from_pretrained(model_path)`` loads it as the reference does
+    (``AutoTokenizer.from_pretrained(path, use_fast=True)``; needs the tokenizer files, which are not in this container), and the
+    constructor takes any object with ``apply_chat_template`` (a ``PreTrainedTokenizerFast`` built in memory in the tests).  As in
+    the reference ``pad_token`` becomes "[PAD]" with id 0.  The chat template must mark assistant turns with
+    ``{% generation %}`` for the mask to be non-trivial (transformers' rule, not this class's).  Output keys and dtypes are the
+    reference's: ``input_ids``, ``loss_mask`` int64 [B, L] on the host; ``make_eagle_batch`` / ``make_eagle_draft_input`` take it from there."""
+
+    def __init__(self, tokenizer) -> None:
+        if not hasattr(tokenizer, "apply_chat_template"):
+            raise TypeError("ChatCollator needs a tokenizer with apply_chat_template (transformers PreTrainedTokenizerFast)")
+        self._tokenizer = tokenizer
+        self._tokenizer.pad_token = "[PAD]"                       # train.py:245-246
+        self._tokenizer.pad_token_id = 0
+
+    @classmethod
+    def from_pretrained(cls, model_path) -> "ChatCollator":
+        import transformers
+        return cls(transformers.AutoTokenizer.from_pretrained(str(model_path), use_fast=True))   # train.py:244
+
+    def __call__(self, features: Sequence[Dict]) -> Dict[str, torch.Tensor]:
+        if not features:
+            raise ValueError("empty batch")
+        result = self._tokenizer.apply_chat_template([m["messages"] for m in features], tokenize=True, add_generation_prompt=False,
+                                                     return_dict=True, return_assistant_tokens_mask=True, return_tensors="pt",
+                                                     padding=True)                                # train.py:249
+        ids = torch.as_tensor(result["input_ids"], dtype=torch.long)
+        mask = torch.as_tensor(result["assistant_masks"], dtype=torch.long)
+        if ids.shape != mask.shape:
+            raise ValueError("the tokenizer returned an assistant mask of another shape than input_ids")
         return {"input_ids": ids, "loss_mask": mask}
 
 

@@ -54,3 +54,43 @@ def test_make_eagle_batch_matches_oracle(max_len):
     d = (got["hidden_states"].float().cpu() - h.float())
     assert float(d.abs().max()) <= 0.1 + 2 ** -6 and float(d.abs().max()) > 0.01
     assert torch.equal(got["target"][:, :-1], got["hidden_states"][:, 1:]) and not got["target"][:, -1].any()
+
+
+def _toy_tokenizer():
+    """A fast tokenizer built in memory (no files): word-level vocabulary, a chat template with {% generation %} marks."""
+    import transformers
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    vocab = {"[PAD]": 0, "<unk>": 1, "<|user|>": 2, "<|assistant|>": 3, "<|end|>": 4}
+    for w in "hello world how are you fine thanks what is the answer forty two".split():
+        vocab[w] = len(vocab)
+    tok = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tok.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    fast = transformers.PreTrainedTokenizerFast(tokenizer_object=tok, unk_token="<unk>")
+    fast.chat_template = ("{% for m in messages %}{% if m['role'] == 'user' %}<|user|> {{ m['content'] }} <|end|> {% else %}"
+                          "<|assistant|> {% generation %}{{ m['content'] }} <|end|> {% endgeneration %}{% endif %}{% endfor %}")
+    return fast
+
+
+def test_chat_collator_is_the_reference_call():
+    """eagle/train.py:242-253: pad token "[PAD]" / id 0, apply_chat_template(..., return_assistant_tokens_mask=True, padding=True),
+    keys input_ids / loss_mask.  Checked against the same transformers call made directly, on an in-memory tokenizer."""
+    from eagle_amd.data import ChatCollator
+    feats = [{"messages": [{"role": "user", "content": "hello how are you"}, {"role": "assistant", "content": "fine thanks"}]},
+             {"messages": [{"role": "user", "content": "what is the answer"}, {"role": "assistant", "content": "forty two"},
+                           {"role": "user", "content": "hello"}, {"role": "assistant", "content": "world"}]}]
+    col = ChatCollator(_toy_tokenizer())
+    out = col(feats)
+    ref_tok = _toy_tokenizer()
+    ref_tok.pad_token = "[PAD]"
+    ref_tok.pad_token_id = 0
+    ref = ref_tok.apply_chat_template([f["messages"] for f in feats], tokenize=True, add_generation_prompt=False, return_dict=True,
+                                      return_assistant_tokens_mask=True, return_tensors="pt", padding=True)
+    assert set(out) == {"input_ids", "loss_mask"} and out["input_ids"].dtype == torch.long and out["loss_mask"].dtype == torch.long
+    assert torch.equal(out["input_ids"], ref["input_ids"]) and torch.equal(out["loss_mask"], torch.as_tensor(ref["assistant_masks"]))
+    assert out["input_ids"].shape == (2, 16) and out["input_ids"][0, 10:].tolist() == [0] * 6      # right-padded with id 0
+    assert out["input_ids"][0, :10].tolist() == [2, 5, 7, 8, 9, 4, 3, 10, 11, 4]                 # <|user|> hello how are you <|end|> <|assistant|> fine thanks <|end|>
+    assert out["loss_mask"][:, :7].sum() == 0 and out["loss_mask"][0, 7:10].tolist() == [1, 1, 1]  # the first assistant turn, not its header
+    with pytest.raises(ValueError):
+        col([])
+    with pytest.raises(TypeError):
+        ChatCollator(object())
