@@ -149,3 +149,18 @@ def make_eagle_draft_input(batch: Dict[str, torch.Tensor], verifier_hidden: torc
     if want_noise:
         out["noise"] = noise
     return out
+
+
+def _make_eagle_input(batch: Dict[str, torch.Tensor], verifier_model, max_model_len: int, transform_uniform_low: float,
+                      transformer_uniform_high: float, device, generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
+    """eagle/train.py:256-269 with its own signature, verifier forward included: truncate to ``max_model_len``, run
+    ``verifier_model(input_ids, output_hidden_states=True, use_cache=False)`` under no_grad, take the last hidden state, add the
+    uniform noise, shift.  ``verifier_model`` is the caller's (any module whose output has ``.hidden_states``, e.g. a transformers
+    causal LM); everything after its forward runs in this library's kernels (``make_eagle_batch``).  Returns the reference's keys."""
+    ids = batch["input_ids"].to(device)[:, :max_model_len]
+    with torch.no_grad():
+        hidden = verifier_model(ids, output_hidden_states=True, use_cache=False).hidden_states[-1]
+    if hidden.dtype != torch.bfloat16:
+        hidden = hidden.to(torch.bfloat16)
+    return make_eagle_batch(batch, hidden.contiguous(), max_model_len, transform_uniform_low, transformer_uniform_high, generator=generator)
+

@@ -94,3 +94,34 @@ def test_chat_collator_is_the_reference_call():
         col([])
     with pytest.raises(TypeError):
         ChatCollator(object())
+
+
+@pytest.mark.gpu
+def test_make_eagle_input_runs_the_verifier_forward_like_the_reference():
+    """eagle/train.py:256-269 end to end: a (tiny, randomly initialised, in-memory) transformers Llama as the verifier, the
+    reference's statements written out on the CPU side, this library's kernels on the device side."""
+    import transformers
+    from eagle_amd.data import _make_eagle_input
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = transformers.LlamaConfig(vocab_size=128, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=4, max_position_embeddings=64)
+    verifier = transformers.LlamaForCausalLM(cfg).to(torch.bfloat16).to(dev).eval()
+    g = torch.Generator().manual_seed(5)
+    batch = Collator()([{"input_ids": torch.randint(1, 128, (n,), generator=g).tolist(), "loss_mask": torch.randint(0, 2, (n,), generator=g).tolist()}
+                        for n in (13, 20, 7)])
+    max_len = 16
+    got = _make_eagle_input(batch, verifier, max_len, 0.0, 0.0, dev)
+    # the reference's statements (train.py:257-268) on the same verifier, noise off
+    ids = batch["input_ids"].to(dev)[:, :max_len]
+    with torch.no_grad():
+        h = verifier(ids, output_hidden_states=True, use_cache=False).hidden_states[-1]
+    target = h.new_zeros(h.shape)
+    target[:, :-1, :] = h[:, 1:, :]
+    shifted = torch.cat((ids[:, 1:], torch.zeros(ids.size(0), 1, dtype=ids.dtype, device=dev)), dim=1)
+    assert torch.equal(got["hidden_states"], h) and torch.equal(got["target"], target)
+    assert torch.equal(got["input_ids"], shifted) and torch.equal(got["loss_mask"].cpu(), batch["loss_mask"][:, :max_len])
+    noisy = _make_eagle_input(batch, verifier, max_len, -0.1, 0.1, dev, generator=torch.Generator(device=dev).manual_seed(2))
+    d = (noisy["hidden_states"].float() - h.float()).abs()
+    assert 0.01 < float(d.max()) <= 0.1 + float(h.float().abs().max()) * 2 ** -7
+    assert torch.equal(noisy["target"][:, :-1], noisy["hidden_states"][:, 1:]) and not noisy["target"][:, -1].any()
