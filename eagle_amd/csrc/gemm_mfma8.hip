@@ -4,7 +4,8 @@
 //   C[M,N] = epilogue( A[M,K] . B[N,K]^T )      same contract as gemm_nt_kernel (gemm_mfma.hip)
 //
 // Why a second kernel: the 128x128 kernel drains its LDS-DMA (vmcnt(0)) at one barrier per K step
-// and tops out near 0.9 PFLOP/s whatever is tuned around it.  Here every K tile is cut into four
+// and tops out near 0.9 PFLOP/s whatever is tuned around it.  The basic structure (PINGPONG = false, the first form of round 1,
+// not launched any more; every launch uses the ping-pong schedules described inside the kernel): every K tile is cut into four
 // phases; each phase issues ONE 16 KB half-tile of a later K tile, multiplies one quadrant of the
 // wave's 128x64 output (16 MFMAs) and ends in a raw s_barrier that waits for LDS traffic only.  The
 // DMA is retired once per K tile by a counted vmcnt that leaves the two youngest half-tiles in
@@ -34,9 +35,9 @@
 #ifndef G8_PRIO_M
 #define G8_PRIO_M 1
 #define G8_PRIO_R 0
-#ifndef G8_SCHED
-#define G8_SCHED 2
 #endif
+#ifndef G8_SCHED
+#define G8_SCHED 2                       // main-loop schedule: 2 = four slots per K tile (see the kernel); 0 / 1 = the eight-slot forms
 #endif
 #define G8_HALF (128 * G8_BK)           // elements per half-tile (16 KB)
 
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
     // Ping-pong schedule: the two waves of a SIMD (wr = 0 / wr = 1 share it) run the same program one
     // barrier apart, so that while one multiplies a quadrant (16 MFMAs) the other issues its LDS
     // fragment reads and its share of the DMA -- the reads no longer sit in front of the MFMAs of
-    // BOTH waves.  Eight slots per K tile (R = reads/DMA, M = MFMA); group wr=1 enters one barrier late:
+    // BOTH waves.  Rounds 1-2 (SCHED 0 / 1, kept for A/B): eight slots per K tile (R = reads/DMA, M = MFMA); group wr=1 enters one barrier late:
     //   S1 R  B(nh0) B(nh1) A(mh0) reads; stage A0(t+1) -> buffer b^1   S2 M  quadrant (0,0)
     //   S3 R  stage A1(t+1) -> buffer b^1                               S4 M  quadrant (0,1)
     //   S5 R  A(mh1) reads; stage B0(t+2) -> buffer b                   S6 M  quadrant (1,1)
@@ -250,7 +251,17 @@ __global__ __launch_bounds__(G8_THREADS) void gemm_nt8_kernel(Gemm8Args p) {
 #define G8_BAR() do { if (!(DBG & 4)) __builtin_amdgcn_s_barrier(); } while (0)
     if (DBG & 2) { read_b(hbuf(0, 2 + (wc >> 1)), 0, bf0); read_a(hbuf(0, wr), 0); read_b(hbuf(0, 2 + (wc >> 1)), 1, bf1); }
     if (SCHED == 2) {
-      // four slots per K tile: 32 MFMAs per M slot, half the barriers; every R slot ends with its LDS reads retired
+      // The shipped schedule (round 3): FOUR slots per K tile -- 32 MFMAs per M slot, half the barriers of the form above
+      // (1.31-1.42 -> 1.39-1.50 PFLOP/s on the step's shapes, profiles/r03_gemm8_schedules.txt):
+      //   S1 R  B(nh0) A(mh0) B(nh1) reads (16); stage A0, A1(t+1) -> buffer b^1; lgkmcnt(0)       S2 M  quadrants (0,0) (0,1)
+      //   S3 R  A(mh1) reads (8); stage B0, B1(t+2) -> buffer b; vmcnt(4) lgkmcnt(0): t+1 landed    S4 M  quadrants (1,1) (1,0)
+      // The partner's M slot is now 512 cycles, long enough for four DMA pieces in one R slot.  Every R slot ends with its
+      // OWN LDS reads retired (lgkmcnt(0) before the barrier), which makes the hazards exact, with interval k = the time
+      // between barriers k-1 and k, early group's S1(t) = interval 4t, late group's = 4t+1:
+      // WAR: the A halves of buffer b^1 were last read in S3(t-1) (early 4t-2, late 4t-1, retired before barrier 4t-1 ends)
+      // and are restaged in S1(t) (early 4t at the earliest); the B halves of buffer b are last read in S1(t) (early 4t, late
+      // 4t+1, retired by the end of 4t+1) and restaged in S3(t) (early 4t+2).  RAW: every wave retires its pieces of tile
+      // t+1 in its S3(t) (late group: interval 4t+3); the first read of tile t+1 is the early group's S1(t+1) = interval 4t+4.
       for (int t = 0; t < nk; ++t) {
         const bf16_t* la = hbuf(t & 1, wr);
         const bf16_t* lb = hbuf(t & 1, 2 + (wc >> 1));
