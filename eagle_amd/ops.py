@@ -224,6 +224,39 @@ def gemm_nt(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_nt_tail_plan(M: int, N: int, K: int, n_cu: int = 256):
+    """(N1, ksplit) when a big NT GEMM is worth cutting into whole rounds of 256x256 tiles + a split-K tail, else None.
+    The 256x256 kernel runs one workgroup per CU: tiles / n_cu rounds, and a last round with few tiles leaves most CUs idle
+    for a whole tile time (lm_head forward, 4096 x 151936: 9504 tiles = 37 rounds + 32 tiles).  Those tail tiles' columns
+    go to a second launch cut ksplit ways along K (as many workgroups as CUs, 1/ksplit of a tile time) + the slab sum."""
+    tm, tn = (M + 255) // 256, (N + 255) // 256
+    total = tm * tn
+    tail = total % n_cu
+    if M % 256 or K % 512 or K < 2048 or total < 8 * n_cu or tail == 0 or tail > n_cu // 2 or tail % tm:
+        return None
+    ks = min(8, n_cu // tail, K // 512)
+    if ks < 2:
+        return None
+    return (tn - tail // tm) * 256, ks
+
+
+def gemm_nt_rounds(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gemm_nt for the very wide products of the training step (the frozen lm_head on 4096 tokens): whole rounds of tiles in
+    one launch, the tail columns split along K (gemm_nt_tail_plan).  The tail columns' sums are formed slice by slice (fp32)
+    instead of in one pass: same value up to fp32 summation order.  Shapes without a wasteful tail take the plain call."""
+    M, K = A.shape
+    N = B.shape[0]
+    plan = gemm_nt_tail_plan(M, N, K)
+    if plan is None:
+        return gemm_nt(A, B, out=out)
+    N1, ks = plan
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=A.device)
+    gemm_nt(A, B[:N1], out=out[:, :N1])
+    gemm_nt(A, B[N1:], out=out[:, N1:], ksplit=ks)
+    return out
+
+
 def gemm_tn_ok(A: torch.Tensor, B: torch.Tensor) -> bool:
     """Shapes eagle_gemm_tn_bf16 takes: A [K, M], B [K, N] row-major, M and N multiples of 256, K a multiple of 64."""
     K, M = A.shape

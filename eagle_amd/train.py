@@ -215,8 +215,8 @@ def loss_fwd_bwd(predict: torch.Tensor, target: torch.Tensor, lm_head: torch.Ten
     """eagle/train.py:106-124 at the logits level.  predict/target [N,D] bf16, lm_head [V,D] bf16
     (frozen), mask [N] fp32.  Returns (sums[4] = {sum m*ploss, sum m*vloss, sum m*agree, sum m},
     dpredict [N,D] = d(scale*(v_w*vloss + p_w*ploss))/d predict or None)."""
-    t_logits = ops.gemm_nt(target, lm_head)
-    o_logits = ops.gemm_nt(predict, lm_head)
+    t_logits = ops.gemm_nt_rounds(target, lm_head)               # whole rounds of tiles + a split-K tail (ops.gemm_nt_tail_plan)
+    o_logits = ops.gemm_nt_rounds(predict, lm_head)
     stats = ops.ce_partial(t_logits, o_logits, 0, predict, target)
     sums, lse_t, lse_o, _ = ops.ce_combine(stats, mask)
     if not want_grad:

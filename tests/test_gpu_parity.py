@@ -822,6 +822,28 @@ def test_gemm_nt_split_k(M, N, K, S):
     close(yf, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().mean()) + 1e-3, what="split-k fp32")
 
 
+def test_gemm_nt_whole_rounds_plus_split_k_tail():
+    """ops.gemm_nt_rounds (the lm_head forward of the training step): the columns of the whole rounds of 256x256 tiles are the
+    plain kernel's bit for bit; the tail columns go through split-K and agree to fp32 summation order; the plan itself for the
+    step's shape (4096 x 151936 x 4096: 37 rounds + 32 tiles -> 592 column tiles + a 384-column tail cut 8 ways)."""
+    from eagle_amd import ops
+    assert ops.gemm_nt_tail_plan(4096, 151936, 4096) == (592 * 256, 8)
+    assert ops.gemm_nt_tail_plan(4096, 24576, 4096) is None and ops.gemm_nt_tail_plan(4096, 4096, 151936) is None
+    M, N, K = 1024, 519 * 256 - 100, 2048                     # 4 x 519 tiles = 8 rounds + 28 tiles: 7 column tiles in the tail
+    assert ops.gemm_nt_tail_plan(M, N, K) == (512 * 256, 4)
+    d = dev()
+    g = torch.Generator(device=d).manual_seed(11)
+    A = torch.randn(M, K, generator=g, device=d).to(BF)
+    Bm = (torch.randn(N, K, generator=g, device=d) / K ** 0.5).to(BF)
+    y = ops.gemm_nt_rounds(A, Bm)
+    y1 = ops.gemm_nt(A, Bm)
+    N1 = 512 * 256
+    assert torch.equal(y[:, :N1], y1[:, :N1])
+    ref = (A[:, :].float() @ Bm[N1:].float().t()).cpu()
+    close(y[:, N1:], ref, what="split-k tail vs fp32")
+    close(y[:, N1:], y1[:, N1:].float().cpu(), rtol=4e-3, atol=float(ref.abs().max()) / 128.0, what="split-k tail vs single pass")
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 4096, 4096), (300, 512, 256), (256, 12288, 4096), (1000, 256, 1536)])
 def test_gemm_nn_k_major_weight(M, N, K):
     """eagle_gemm_nn_bf16 (the data gradients: dX = dY . W with W read as stored, through transposing LDS reads) against
