@@ -19,7 +19,7 @@
 #define TK_WCHUNK 1024                 // logits per wave in stage 1
 #define TK_PER_LANE (TK_WCHUNK / 64)   // 16
 #define TK_MAXK 16
-#define TK_CM 8                        // stage-2 candidates per thread -> wavechunks*k <= 2048
+#define TK_CM 8                        // stage-2 candidates per thread (16 beyond 2048 candidates) -> wavechunks*k <= 4096
 
 __device__ __forceinline__ uint32_t mono_bf16(bf16_t b) {  // 16-bit monotone key in the low half
   if ((b & 0x7fff) > 0x7f80) return 0xffffu;       // NaN: largest
@@ -631,7 +631,8 @@ static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int 
   if (block_index && block_rows < rows) return EAGLE_ERR_SHAPE;
   if (rows < 1 || V < 1 || k < 1 || k > TK_MAXK || ld < V) return EAGLE_ERR_SHAPE;
   const int nwc = (V + TK_WCHUNK - 1) / TK_WCHUNK;
-  if ((int64_t)nwc * k > TK_THREADS * TK_CM) return EAGLE_ERR_SHAPE;
+  if ((int64_t)nwc * k > TK_THREADS * 16) return EAGLE_ERR_SHAPE;     // stage 2 holds 8 (<= 2048 candidates) or 16 per thread
+  const bool big = (int64_t)nwc * k > TK_THREADS * TK_CM;             // > 2048 candidates: V > 131072 at k > 13 (k = 16 over 151936)
   unsigned long long* cand = (unsigned long long*)workspace;
   float2* part = lse_out ? reinterpret_cast<float2*>(cand + (int64_t)rows * nwc * k) : nullptr;
   dim3 g1((nwc + 3) / 4, rows);
@@ -651,6 +652,10 @@ static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int 
   } else if (dtype == 0 && lse_out) {
     hipLaunchKernelGGL(topk_stage1_bf16_kernel<true>, g1, dim3(TK_THREADS), 0, stream, (const bf16_t*)logits, ld, V, k, nwc, cand,
                        block_index, block_rows, part);
+    if (big)
+      hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, true, false, 16>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+                         (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
+    else
     hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, true>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                        (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
   } else if (dtype == 0) {
@@ -659,11 +664,19 @@ static int topk_launch(const void* logits, int64_t ld, int dtype, int rows, int 
     if (V <= 65536)
       hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false, true>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                          (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
+    else if (big)
+      hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false, false, 16>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+                         (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
     else
       hipLaunchKernelGGL((topk_stage2_kernel<bf16_t, false>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                          (const bf16_t*)logits, ld, out_idx, (bf16_t*)out_val, block_index, block_rows, part, nwc, lse_out, out_group, out_gstride);
   } else if (dtype == 1 && !lse_out) {
     hipLaunchKernelGGL(topk_stage1_f32_kernel, g1, dim3(TK_THREADS), 0, stream, (const float*)logits, ld, V, k, nwc, cand, block_index, block_rows);
+    if (big)
+      hipLaunchKernelGGL((topk_stage2_kernel<float, false, false, 16>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
+                         (const float*)logits, ld, out_idx, (float*)out_val, block_index, block_rows, (const float2*)nullptr, nwc,
+                         (float*)nullptr, out_group, out_gstride);
+    else
     hipLaunchKernelGGL((topk_stage2_kernel<float, false>), dim3(rows), dim3(TK_THREADS), 0, stream, cand, nwc * k, k,
                        (const float*)logits, ld, out_idx, (float*)out_val, block_index, block_rows, (const float2*)nullptr, nwc,
                        (float*)nullptr, out_group, out_gstride);

@@ -753,9 +753,9 @@ def _rows_d(x, name, N):
 
 
 def topk_limit_check(V: int, k: int) -> None:
-    """eagle_topk_vocab merges ceil(V/1024)*k stage-1 candidates per row in one 256-thread workgroup (<= 2048)."""
-    if not 1 <= k <= 16 or ((V + 1023) // 1024) * k > 2048:
-        raise ValueError(f"top-{k} over a {V}-entry vocabulary exceeds the kernel's limits (k <= 16, ceil(V/1024)*k <= 2048)")
+    """eagle_topk_vocab merges ceil(V/1024)*k stage-1 candidates per row in one 256-thread workgroup (<= 4096)."""
+    if not 1 <= k <= 16 or ((V + 1023) // 1024) * k > 4096:
+        raise ValueError(f"top-{k} over a {V}-entry vocabulary exceeds the kernel's limits (k <= 16, ceil(V/1024)*k <= 4096)")
 
 
 def ce_partial(t_logits, o_logits, v0: int = 0, predict=None, target=None):

@@ -258,6 +258,29 @@ def test_topk_bit_exact(rows, V, dtype):
         lib().eagle_debug_set_topk(0)
 
 
+@pytest.mark.parametrize("V,k", [(151936, 16), (151936, 14), (262144, 16), (131072, 16)])
+def test_topk_more_than_2048_stage1_candidates(V, k):
+    """k = 16 over the Qwen3 vocabulary leaves 149 x 16 = 2384 stage-1 candidates per row (up to 4096 are taken: the merge then
+    holds 16 per thread): ids and values of the stable-sort oracle in bf16, with the row log-sum-exp, and in fp32."""
+    from eagle_amd import ops
+    g = torch.Generator().manual_seed(V + k)
+    x = (torch.randn(3, V, generator=g) * 4).to(BF)
+    x[1, ::5] = x[1, 0]                                              # long runs of ties
+    ev, ei = ot.stable_topk(x, k)
+    v, i = ops.topk(x.to(dev()), k)
+    assert torch.equal(i.cpu(), ei) and torch.equal(v.cpu(), ev)
+    lse = torch.empty(3, dtype=torch.float32, device=dev())
+    v, i = ops.topk(x.to(dev()), k, lse_out=lse)
+    assert torch.equal(i.cpu(), ei) and torch.equal(v.cpu(), ev)
+    assert torch.allclose(lse.cpu(), torch.logsumexp(x.float(), dim=1), rtol=1e-5, atol=1e-4)
+    xf = torch.randn(3, V, generator=g) * 4
+    ev, ei = ot.stable_topk(xf, k)
+    v, i = ops.topk(xf.to(dev()), k)
+    assert torch.equal(i.cpu(), ei) and torch.equal(v.cpu(), ev)
+    with pytest.raises(ValueError):
+        ops.topk_limit_check(300000, 16)                             # 293 x 16 > 4096
+
+
 @pytest.mark.parametrize("rows,V", [(1, 32000), (8, 32000), (3, 151936), (5, 1000), (2, 4097)])
 def test_topk_with_row_lse_from_the_same_pass(rows, V):
     """eagle_topk_lse_vocab: ids / values bit-exact as eagle_topk_vocab, lse against fp32 torch.logsumexp and the
