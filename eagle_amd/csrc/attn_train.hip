@@ -74,7 +74,7 @@ __device__ __forceinline__ int a2_off(int row, int ch) {   // byte offset of 16-
 }
 
 template <bool PAIR>
-__global__ __launch_bounds__(AT_THREADS) void attn_train_fwd2_kernel(AttnTrainArgs p) {
+__global__ __launch_bounds__(AT_THREADS, 2) void attn_train_fwd2_kernel(AttnTrainArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][A2_KB * 256];   // [buffer][K|V] 64 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int D = p.H * AT_HD, L = p.L;
@@ -142,35 +142,17 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd2_kernel(AttnTrainAr
       // all 16 K fragments are requested before the first MFMA (one wave per SIMD: nothing else
       // hides the LDS latency); d-step outermost: 8 independent accumulators between two MFMAs on
       // the same one
-      bf16x8 kfr[4][4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 kfr[4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) kfr[s][kt] = *reinterpret_cast<const bf16x8*>(Kt + a2_off(16 * kt + r16, 4 * s + g));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int kt = 0; kt < 4; ++kt) kfr[kt] = *reinterpret_cast<const bf16x8*>(Kt + a2_off(16 * kt + r16, 4 * s + g));
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-          sc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[s][kt], qf[0][s], sc[kt][0], 0, 0, 0);
-          sc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[s][kt], qf[1][s], sc[kt][1], 0, 0, 0);
+          sc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt], qf[0][s], sc[kt][0], 0, 0, 0);
+          sc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[kt], qf[1][s], sc[kt][1], 0, 0, 0);
         }
-      // the V^T fragments of this tile are requested now, ahead of the softmax arithmetic
-      bf16x8 vfr[2][8];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int dt = 0; dt < 8; ++dt) {
-          const int r0 = 32 * ks + 4 * g + tq;
-          const a2_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) a2_s4*)(Vt + a2_off(r0, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
-          const a2_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) a2_s4*)(Vt + a2_off(r0 + 16, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
-          union { struct { a2_s4 a, b; } s; bf16x8 v; } u;
-          u.s.a = lo; u.s.b = hi;
-          vfr[ks][dt] = u.v;
-        }
-      __builtin_amdgcn_sched_barrier(0);
+      }
       const bool need_mask = (k0 + A2_KB - 1 > qw) || (k0 + A2_KB > L);   // wave-uniform
       bf16x8 pf[2][2];
 #pragma unroll
@@ -221,8 +203,15 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_fwd2_kernel(AttnTrainAr
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int dt = 0; dt < 8; ++dt) {
-          o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[ks][dt], pf[0][ks], o[dt][0], 0, 0, 0);
-          o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vfr[ks][dt], pf[1][ks], o[dt][1], 0, 0, 0);
+          const int r0 = 32 * ks + 4 * g + tq;
+          const a2_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) a2_s4*)(Vt + a2_off(r0, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
+          const a2_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) a2_s4*)(Vt + a2_off(r0 + 16, 2 * dt + (tp >> 1)) + 8 * (tp & 1)));
+          union { struct { a2_s4 a, b; } s; bf16x8 v; } u;
+          u.s.a = lo; u.s.b = hi;
+          o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[0][ks], o[dt][0], 0, 0, 0);
+          o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.v, pf[1][ks], o[dt][1], 0, 0, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // next tile landed (this thread's share) ...
