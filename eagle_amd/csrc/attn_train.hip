@@ -292,7 +292,7 @@ __device__ __forceinline__ bf16x8 a2_tr_frag(const char* tile, int ks, int dt, i
 }
 
 // dQ (query stationary): 128 queries per pass (32 per wave), 64-key tiles of K and V.
-__global__ __launch_bounds__(AT_THREADS) void attn_train_dq2_kernel(AttnTrainArgs p) {
+__global__ __launch_bounds__(AT_THREADS, 2) void attn_train_dq2_kernel(AttnTrainArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][A2_KB * 256];   // [buffer][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, g = lane >> 4;
   const int tq = (lane & 15) >> 2, tp = lane & 3;
@@ -336,56 +336,52 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_dq2_kernel(AttnTrainArg
       const char* Kt = &lds[t & 1][0][0];
       const char* Vt = &lds[t & 1][1][0];
       if (k0 <= qw + 31) {
-        f32x4 sc[4][2], dp[4][2];
-#pragma unroll
-        for (int kt = 0; kt < 4; ++kt) { sc[kt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[kt][1] = sc[kt][0]; dp[kt][0] = sc[kt][0]; dp[kt][1] = sc[kt][0]; }
-        bf16x8 kfr[4][4], vrr[4][4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            kfr[s][kt] = a2_row_frag(Kt, 16 * kt + r16, 4 * s + g);
-            vrr[s][kt] = a2_row_frag(Vt, 16 * kt + r16, 4 * s + g);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            sc[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[s][kt], qf[0][s], sc[kt][0], 0, 0, 0);
-            sc[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[s][kt], qf[1][s], sc[kt][1], 0, 0, 0);
-            dp[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vrr[s][kt], dof[0][s], dp[kt][0], 0, 0, 0);
-            dp[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vrr[s][kt], dof[1][s], dp[kt][1], 0, 0, 0);
-          }
-        bf16x8 ktf[2][8];                       // K^T fragments: requested ahead of the exp arithmetic
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int dt = 0; dt < 8; ++dt) ktf[ks][dt] = a2_tr_frag(Kt, ks, dt, g, tq, tp);
-        __builtin_amdgcn_sched_barrier(0);
+        // The 64-key tile in two halves of 32 keys (= one 32-wide k step of the dQ product each): scores, dP, dS and the
+        // dQ update of a half before the next half starts, fragments read right before their MFMAs.  Half the live score /
+        // dP registers and no fragment arrays: 2 workgroups per CU instead of 1 (the all-at-once form needs 400 registers).
         const bool need_mask = (k0 + A2_KB - 1 > qw) || (k0 + A2_KB > L);
-        bf16x8 dsf[2][2];
 #pragma unroll
-        for (int qg = 0; qg < 2; ++qg) {
-          const int qi = qw + 16 * qg + r16;
+        for (int ks = 0; ks < 2; ++ks) {
+          f32x4 sc[2][2], dp[2][2];
 #pragma unroll
-          for (int kt = 0; kt < 4; ++kt)
+          for (int j = 0; j < 2; ++j) { sc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[j][1] = sc[j][0]; dp[j][0] = sc[j][0]; dp[j][1] = sc[j][0]; }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float pr = __builtin_amdgcn_exp2f(fmaf(sc[kt][qg][r], p.scale2, nlse[qg]));
-              if (need_mask) { const int key = k0 + 16 * kt + 4 * g + r; pr = (key <= qi && key < L) ? pr : 0.f; }
-              sc[kt][qg][r] = pr * (dp[kt][qg][r] - dl[qg]);
+          for (int s = 0; s < 4; ++s) {
+            bf16x8 kfr[2], vrr[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              kfr[j] = a2_row_frag(Kt, 16 * (2 * ks + j) + r16, 4 * s + g);
+              vrr[j] = a2_row_frag(Vt, 16 * (2 * ks + j) + r16, 4 * s + g);
             }
-          dsf[qg][0] = pack_frag(sc[0][qg], sc[1][qg]);
-          dsf[qg][1] = pack_frag(sc[2][qg], sc[3][qg]);
-        }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int j = 0; j < 2; ++j) {
+              sc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[j], qf[0][s], sc[j][0], 0, 0, 0);
+              sc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr[j], qf[1][s], sc[j][1], 0, 0, 0);
+              dp[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vrr[j], dof[0][s], dp[j][0], 0, 0, 0);
+              dp[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vrr[j], dof[1][s], dp[j][1], 0, 0, 0);
+            }
+          }
+          bf16x8 dsf[2];
+#pragma unroll
+          for (int qg = 0; qg < 2; ++qg) {
+            const int qi = qw + 16 * qg + r16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float pr = __builtin_amdgcn_exp2f(fmaf(sc[j][qg][r], p.scale2, nlse[qg]));
+                if (need_mask) { const int key = k0 + 16 * (2 * ks + j) + 4 * g + r; pr = (key <= qi && key < L) ? pr : 0.f; }
+                sc[j][qg][r] = pr * (dp[j][qg][r] - dl[qg]);
+              }
+            dsf[qg] = pack_frag(sc[0][qg], sc[1][qg]);
+          }
 #pragma unroll
           for (int dt = 0; dt < 8; ++dt) {
-            dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[ks][dt], dsf[0][ks], dq[dt][0], 0, 0, 0);
-            dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[ks][dt], dsf[1][ks], dq[dt][1], 0, 0, 0);
+            const bf16x8 ktf = a2_tr_frag(Kt, ks, dt, g, tq, tp);
+            dq[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[0], dq[dt][0], 0, 0, 0);
+            dq[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf[1], dq[dt][1], 0, 0, 0);
           }
+        }
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -462,61 +458,63 @@ __global__ __launch_bounds__(AT_THREADS) void attn_train_dkv2_kernel(AttnTrainAr
       const float* lse_s = reinterpret_cast<const float*>(Qt + 2 * A2_TILE_BYTES);
       const float* dl_s = lse_s + A2_KB;
       if (q0 + A2_KB - 1 >= kw) {                  // wave-uniform: some query of the tile sees this wave's keys
-        f32x4 sc[4][2], dp[4][2];
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) { sc[qt][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[qt][1] = sc[qt][0]; dp[qt][0] = sc[qt][0]; dp[qt][1] = sc[qt][0]; }
-        f32x4 lser[4], dlr[4];                     // this lane's rows 4g..4g+3 of each 16-query tile
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-          lser[qt] = *reinterpret_cast<const f32x4*>(lse_s + 16 * qt + 4 * g);
-          dlr[qt] = *reinterpret_cast<const f32x4*>(dl_s + 16 * qt + 4 * g);
-        }
-        // fragments are read one 32-wide k step at a time, right before their MFMAs: holding all four steps of Q and dO (128
-        // registers) beside the 128 accumulators and the K / V fragments spilled (324 B of scratch per lane at the 256-register cap)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          bf16x8 qr[4], orw[4];
-#pragma unroll
-          for (int qt = 0; qt < 4; ++qt) {
-            qr[qt] = a2_row_frag(Qt, 16 * qt + r16, 4 * s + g);
-            orw[qt] = a2_row_frag(Ot, 16 * qt + r16, 4 * s + g);
-          }
-#pragma unroll
-          for (int qt = 0; qt < 4; ++qt) {
-            sc[qt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[qt], kf[0][s], sc[qt][0], 0, 0, 0);   // S[q][key]: rows = queries
-            sc[qt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[qt], kf[1][s], sc[qt][1], 0, 0, 0);
-            dp[qt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orw[qt], vf[0][s], dp[qt][0], 0, 0, 0);  // dP = dO . V^T
-            dp[qt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orw[qt], vf[1][s], dp[qt][1], 0, 0, 0);
-          }
-        }
+        // The 64-query tile in two halves of 32 queries (= one 32-wide k step of the dV / dK products each): scores, dP, P, dS
+        // and the two updates of a half before the next half starts, fragments read right before their MFMAs (holding every
+        // fragment of the tile spilled at 256 registers and needs 450 without a cap): 2 workgroups per CU.
         const bool need_mask = (q0 < kw + 31) || (q0 + A2_KB > L);   // tile touches the diagonal / the end
-        bf16x8 pf[2][2], dsf[2][2];
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-          const int ki = kw + 16 * kg + r16;
-          f32x4 pr[4], dsv[4];
+        for (int ks = 0; ks < 2; ++ks) {
+          f32x4 sc[2][2], dp[2][2];
 #pragma unroll
-          for (int qt = 0; qt < 4; ++qt)
+          for (int j = 0; j < 2; ++j) { sc[j][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; sc[j][1] = sc[j][0]; dp[j][0] = sc[j][0]; dp[j][1] = sc[j][0]; }
+          f32x4 lser[2], dlr[2];                     // this lane's rows 4g..4g+3 of each 16-query tile of the half
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float e = __builtin_amdgcn_exp2f(fmaf(sc[qt][kg][r], p.scale2, -lser[qt][r]));
-              if (need_mask) { const int qi = q0 + 16 * qt + 4 * g + r; e = (ki <= qi && qi < L && ki < L) ? e : 0.f; }
-              pr[qt][r] = e;
-              dsv[qt][r] = e * (dp[qt][kg][r] - dlr[qt][r]);
+          for (int j = 0; j < 2; ++j) {
+            lser[j] = *reinterpret_cast<const f32x4*>(lse_s + 16 * (2 * ks + j) + 4 * g);
+            dlr[j] = *reinterpret_cast<const f32x4*>(dl_s + 16 * (2 * ks + j) + 4 * g);
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            bf16x8 qr[2], orw[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              qr[j] = a2_row_frag(Qt, 16 * (2 * ks + j) + r16, 4 * s + g);
+              orw[j] = a2_row_frag(Ot, 16 * (2 * ks + j) + r16, 4 * s + g);
             }
-          pf[kg][0] = pack_frag(pr[0], pr[1]);   pf[kg][1] = pack_frag(pr[2], pr[3]);
-          dsf[kg][0] = pack_frag(dsv[0], dsv[1]); dsf[kg][1] = pack_frag(dsv[2], dsv[3]);
-        }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int j = 0; j < 2; ++j) {
+              sc[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[j], kf[0][s], sc[j][0], 0, 0, 0);   // S[q][key]: rows = queries
+              sc[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qr[j], kf[1][s], sc[j][1], 0, 0, 0);
+              dp[j][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orw[j], vf[0][s], dp[j][0], 0, 0, 0);  // dP = dO . V^T
+              dp[j][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(orw[j], vf[1][s], dp[j][1], 0, 0, 0);
+            }
+          }
+          bf16x8 pf[2], dsf[2];
+#pragma unroll
+          for (int kg = 0; kg < 2; ++kg) {
+            const int ki = kw + 16 * kg + r16;
+            f32x4 pr[2], dsv[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float e = __builtin_amdgcn_exp2f(fmaf(sc[j][kg][r], p.scale2, -lser[j][r]));
+                if (need_mask) { const int qi = q0 + 16 * (2 * ks + j) + 4 * g + r; e = (ki <= qi && qi < L && ki < L) ? e : 0.f; }
+                pr[j][r] = e;
+                dsv[j][r] = e * (dp[j][kg][r] - dlr[j][r]);
+              }
+            pf[kg] = pack_frag(pr[0], pr[1]);
+            dsf[kg] = pack_frag(dsv[0], dsv[1]);
+          }
 #pragma unroll
           for (int dt = 0; dt < 8; ++dt) {
             const bf16x8 otf = a2_tr_frag(Ot, ks, dt, g, tq, tp), qtf = a2_tr_frag(Qt, ks, dt, g, tq, tp);
-            dv[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[0][ks], dv[dt][0], 0, 0, 0);
-            dv[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[1][ks], dv[dt][1], 0, 0, 0);
-            dk[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[0][ks], dk[dt][0], 0, 0, 0);
-            dk[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[1][ks], dk[dt][1], 0, 0, 0);
+            dv[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[0], dv[dt][0], 0, 0, 0);
+            dv[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(otf, pf[1], dv[dt][1], 0, 0, 0);
+            dk[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[0], dk[dt][0], 0, 0, 0);
+            dk[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qtf, dsf[1], dk[dt][1], 0, 0, 0);
           }
+        }
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
