@@ -83,14 +83,29 @@ __global__ __launch_bounds__(256) void colsum_bf16_stage1(const bf16_t* __restri
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = acc[j];
 }
-__global__ void colsum_stage2(const float* __restrict__ part, int nb, int C, bf16_t* __restrict__ out_bf, float* __restrict__ out_f,
-                              int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * C + c];
-  if (out_f) out_f[c] = accumulate ? out_f[c] + s : s;
-  if (out_bf) out_bf[c] = f2bf(accumulate ? bf2f(out_bf[c]) + s : s);
+// 64 columns per workgroup: thread (cx, ry) sums the partial rows ry, ry + 16, ... of its 4 columns (coalesced 256-byte row
+// segments), the 16 row groups meet in LDS.  C % 4 == 0.
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int nb, int C, bf16_t* __restrict__ out_bf,
+                                                    float* __restrict__ out_f, int accumulate) {
+  __shared__ float4 sh[16][16];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cx * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+    for (int b = ry; b < nb; b += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (int64_t)b * C + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  }
+  sh[ry][cx] = s;
+  __syncthreads();
+  if (ry != 0 || c >= C) return;
+  for (int r = 1; r < 16; ++r) { const float4 v = sh[r][cx]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+  const float y[4] = {s.x, s.y, s.z, s.w};
+  for (int j = 0; j < 4; ++j) {
+    if (out_f) out_f[c + j] = accumulate ? out_f[c + j] + y[j] : y[j];
+    if (out_bf) out_bf[c + j] = f2bf(accumulate ? bf2f(out_bf[c + j]) + y[j] : y[j]);
+  }
 }
 
 // AdamW (decoupled weight decay, torch.optim.AdamW semantics: eagle/train.py:66) over one flat
@@ -335,7 +350,7 @@ extern "C" int eagle_silu_mul_bwd_bf16(const void* gu, int64_t ld, const void* d
   return eagle_check_launch();
 }
 
-#define CS_ROWS 64
+#define CS_ROWS 16                      // rows per stage-1 workgroup: 512 workgroups at 4096 tokens x 4096 columns (64 rows: 128 workgroups of serial loads)
 extern "C" int64_t eagle_colsum_workspace_bytes(int N, int C) { return (int64_t)((N + CS_ROWS - 1) / CS_ROWS) * C * 4; }
 extern "C" int eagle_colsum_bf16(const void* x, int64_t ld, int N, int C, void* out_bf16, float* out_f32, int accumulate,
                                  void* workspace, hipStream_t stream) {
@@ -346,7 +361,7 @@ extern "C" int eagle_colsum_bf16(const void* x, int64_t ld, int N, int C, void* 
                      (float*)workspace, N, C, CS_ROWS);
   int rc = eagle_check_launch();
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)workspace, nb, C, (bf16_t*)out_bf16,
+  hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, stream, (const float*)workspace, nb, C, (bf16_t*)out_bf16,
                      out_f32, accumulate);
   return eagle_check_launch();
 }
