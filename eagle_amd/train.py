@@ -229,11 +229,12 @@ def loss_fwd_bwd(predict: torch.Tensor, target: torch.Tensor, lm_head: torch.Ten
 
 def lm_dgrad_ksplit(M: int, N: int, K: int) -> int:
     """dpredict = dlogits[M,V] . lm_head[V,D] has few 256x256 output tiles (M/256 * D/256) and a very
-    long K = V: split K so that two full rounds of workgroups cover the 256 CUs."""
+    long K = V: split K only as far as one round of workgroups needs to cover the 256 CUs (tools/dgrad_ksplit_bench.py, 4096
+    tokens = 256 tiles: 1 slice 3,440 us, 2 slices 3,494, 4 slices 3,649 -- every slice more is another fp32 slab to write and sum)."""
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
-    if tiles >= 512 or K < 16384:
+    if tiles >= 256 or K < 16384:
         return 1
-    return max(1, min(16, 512 // tiles))
+    return max(1, min(16, 256 // tiles))
 
 
 # ---------------------------------------------------------------------------------------------
