@@ -232,7 +232,7 @@ def gemm_nt_tail_plan(M: int, N: int, K: int, n_cu: int = 256):
     tm, tn = (M + 255) // 256, (N + 255) // 256
     total = tm * tn
     tail = total % n_cu
-    if M % 256 or K % 512 or K < 2048 or total < 8 * n_cu or tail == 0 or tail > n_cu // 2 or tail % tm:
+    if M % 256 or K % 512 or K < 2048 or total < n_cu or tail == 0 or tail > n_cu // 2 or tail % tm:
         return None
     ks = min(8, n_cu // tail, K // 512)
     if ks < 2:

@@ -136,7 +136,7 @@ def draft_fwd(W: LayerWeights, emb: torch.Tensor, ids: torch.Tensor, hidden: tor
     if x0 is None:
         x0 = ops.embed_concat(emb, ids, hidden)                   # cat(embed(ids), hidden)      :515,:537-542
     x = ops.gemm_nt(x0, W.fc_w, bias=W.fc_b)                      # fc                           :542
-    qkv = ops.gemm_nt(x, W.wqkv)                                  # q|k|v projections            :222-224
+    qkv = ops.gemm_nt_rounds(x, W.wqkv)                           # q|k|v projections            :222-224 (1.5 rounds of tiles at Qwen3 dims: the half round split along K)
     ops.rope_qk_(qkv, cos, sin, L, 2 * H, hd, position_ids=position_ids)        # :228-233
     attn, lse = ops.attn_train_fwd(qkv, B, L, H, hd)              # causal softmax(QK^T/sqrt d)V :247-273
     h1 = ops.gemm_nt(attn, W.wo, res=x)                           # o_proj + residual            :280,:385

@@ -3,7 +3,9 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from eagle_amd import ops
 dev = torch.device("cuda:0")
-M, N, K = 4096, 151936, 4096
+import sys as _s
+M, N, K = (4096, 151936, 4096) if len(_s.argv) < 4 else tuple(int(v) for v in _s.argv[1:4])
+print("shape", M, N, K, "plan", ops.gemm_nt_tail_plan(M, N, K))
 A = torch.randn(M, K, device=dev).to(torch.bfloat16); B = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
 C = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
 res = {"one launch": [], "rounds + tail": []}
